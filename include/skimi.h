@@ -1,0 +1,169 @@
+/*
+ * skimi.h — C-ABI of libskimi.so, the MI355X (gfx950 / CDNA4) hot path of the
+ * skiing multi-view 3D-pose pipeline.
+ *
+ * The reference (ChenKaiXuSan/Skiing_Analysis_PyTorch) has no FFI of its own: its
+ * boundary for this path is two Python call sites,
+ *     preds = self.vggt(imgs)                       vggt/vggt/infer.py:84
+ *     predicted_3d_pos = model_pos(inputs_2d)       VideoPose3D/run.py:974
+ * and two weight formats (flat state_dicts, vggt/vggt/infer.py:62-67 and
+ * VideoPose3D/run.py:286-289).  Every entry point below is what a ctypes stub at
+ * those call sites binds; each one names the reference
+ * function it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary;
+ *   - every pointer marked "dev" is a device (HBM) address, "host" a host address;
+ *   - every call is asynchronous on the given hipStream_t (passed as void*; NULL =
+ *     the null stream), never synchronises the host, never allocates in the launch
+ *     path (handles allocate once at create/finalize time);
+ *   - return value 0 = ok, negative = error; skimi_last_error() returns the text of
+ *     the calling thread's last error;
+ *   - activations are row-major, channels-last ("NHWC" for images / feature maps,
+ *     [tokens, channels] for token streams).
+ */
+#ifndef SKIMI_H
+#define SKIMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKIMI_OK 0
+#define SKIMI_ERR_ARG (-1)      /* bad argument / shape mismatch */
+#define SKIMI_ERR_HIP (-2)      /* HIP runtime error */
+#define SKIMI_ERR_STATE (-3)    /* handle not finalized / missing weight */
+#define SKIMI_ERR_WORKSPACE (-4)/* workspace too small */
+
+/* element types of buffers that cross the ABI */
+#define SKIMI_F32 0
+#define SKIMI_BF16 1
+
+/* arithmetic mode of the MFMA contractions
+ *   SKIMI_PREC_BF16   : operands rounded to bf16, one v_mfma_f32_32x32x16_bf16 per
+ *                       k-step, fp32 accumulate (the reference's GPU autocast mode,
+ *                       vggt/vggt/infer.py:78-84)
+ *   SKIMI_PREC_BF16X3 : operands kept in fp32 in HBM, split hi+lo into two bf16 while
+ *                       staged to LDS, three MFMAs per k-step (hi*hi + hi*lo + lo*hi):
+ *                       ~2^-17 relative operand error, the mode that meets the 1e-3
+ *                       parity bar against the fp32 CPU reference */
+#define SKIMI_PREC_BF16 0
+#define SKIMI_PREC_BF16X3 1
+
+/* activation in the GEMM epilogue */
+#define SKIMI_ACT_NONE 0
+#define SKIMI_ACT_RELU 1
+#define SKIMI_ACT_GELU 2   /* erf form, torch.nn.GELU() default (vggt/vggt/layers/mlp.py:26) */
+#define SKIMI_ACT_SILU 3
+
+const char* skimi_last_error(void);
+int skimi_version(void);
+/* number of HIP devices visible; does not initialise a context on any */
+int skimi_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* Generic fused contraction  out = epilogue( gather(A) . W^T )               */
+/* Replaces torch.nn.Linear / Conv1d / Conv2d / ConvTranspose2d(k==s) on the  */
+/* path (vggt/vggt/layers/{attention,mlp,patch_embed}.py, heads/dpt_head.py,  */
+/* VideoPose3D/common/model.py:126-138).                                      */
+/* ------------------------------------------------------------------------- */
+typedef struct skimi_gemm_desc {
+    int32_t M, N, K;          /* out rows, out cols, contraction length (K % 8 == 0) */
+    const void* A;            /* dev; [rows, lda] f32 or bf16, channels-last */
+    const void* W;            /* dev; [N, ldw] f32 (BF16X3) or bf16 (BF16): nn.Linear layout */
+    int32_t a_dtype, w_dtype; /* SKIMI_F32 / SKIMI_BF16 */
+    int64_t lda, ldw;         /* in elements */
+    int32_t prec;             /* SKIMI_PREC_* */
+    /* A gather: a_mode 0 = plain rows; 1 = implicit im2col of a channels-last image
+     * [cN, cH, cW, cC] with a KH x KW window (tap-major K: k = (ky*KW+kx)*cC + c),
+     * M = cN*OH*OW, K = KH*KW*cC, cC % BK == 0 (BK = 64 for BF16, 32 for BF16X3) */
+    int32_t a_mode;
+    int32_t cN, cH, cW, cC, KH, KW, stride, pad, dil, OH, OW;
+    /* epilogue: v = acc + bias[n]; v = act(v); v *= gamma[n]; v += resid[m', n];
+     * resid row m' = m + resid_row_off (+ (m / resid_rows_per_batch) * resid_batch_skip) */
+    const float* bias;        /* dev [N] or NULL */
+    const float* gamma;       /* dev [N] or NULL */
+    const float* resid;       /* dev or NULL */
+    int64_t ldr;
+    int32_t resid_rows_per_batch; /* 0 = no batching of the residual row map */
+    int64_t resid_batch_stride;   /* rows between consecutive batches in resid */
+    int64_t resid_row_off;
+    int32_t act;
+    /* store: store_mode 0 = out[m*ldo + n]; 1 = ConvTranspose2d with kernel == stride
+     * (ps_s): m = (img, iy, ix) over [cN, cH, cW], n = (a*ps_s + b)*ps_C + co,
+     * out[((img*cH*ps_s + iy*ps_s + a)*cW*ps_s + ix*ps_s + b)*ldo + co] */
+    void* out;                /* dev; f32 or bf16 */
+    void* out2;               /* dev or NULL: second copy in the other dtype (same indexing, ldo2) */
+    int32_t out_dtype;
+    int64_t ldo, ldo2;
+    int32_t store_mode, ps_s, ps_C;
+    /* optional caller-owned fp32 scratch of >= M*N*4 bytes: lets skinny shapes (too few
+     * output tiles to fill 256 CUs) run split-K; NULL = never split.  force_splitk > 0
+     * pins the split count (tests). */
+    void* splitk_scratch;
+    uint64_t splitk_scratch_bytes;
+    int32_t force_splitk;
+} skimi_gemm_desc;
+
+int skimi_gemm(const skimi_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Row-wise ops on token streams                                              */
+/* ------------------------------------------------------------------------- */
+/* LayerNorm over the last dim C of x[rows, C] (optionally the concatenation of two
+ * sources x and x2 of C/2 channels each: the [frame | global] intermediates of
+ * vggt/vggt/models/aggregator.py:250-253).  out dtype f32 or bf16.
+ * Replaces torch.nn.LayerNorm (block.py:49,66; dpt_head.py:56,223). gamma/beta may be
+ * NULL (elementwise_affine=False, heads/camera_head.py:66). */
+int skimi_layernorm(const float* x, const float* x2, int64_t ldx, int64_t rows, int32_t C,
+                    const float* gamma, const float* beta, float eps,
+                    void* out, int32_t out_dtype, int64_t ldo, void* stream);
+
+/* q/k LayerNorm(head_dim) + 2D RoPE applied in place on a packed qkv buffer
+ * [tokens, 3, heads, 64] (f32 or bf16).  pos is dev int32 [tokens, 2] (y, x);
+ * rope_cos/rope_sin are dev f32 [rope_npos, 16] tables (cos/sin of pos * 1/base^(i/16),
+ * built on the host as rope.py:86-117 does).  Replaces attention.py:54-58 +
+ * rope.py:154-188.  qn_w/kn_w NULL = no norm; pos NULL = no rope. */
+int skimi_qknorm_rope(void* qkv, int32_t dtype, int64_t tokens, int32_t heads,
+                      const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b,
+                      float eps, const int32_t* pos, const float* rope_cos, const float* rope_sin,
+                      int32_t rope_npos, void* stream);
+
+/* Scaled-dot-product attention, no mask, softmax scale 1/sqrt(head_dim)
+ * (F.scaled_dot_product_attention, attention.py:60-61).
+ * qkv: [batch*seq, 3, heads, head_dim]; out: [batch*seq, heads*head_dim], same dtype.
+ * dtype bf16 + head_dim 64 runs the MFMA flash kernel; f32 runs the exact fp32 kernel. */
+int skimi_attention(const void* qkv, void* out, int32_t dtype, int32_t batch, int32_t seq,
+                    int32_t heads, int32_t head_dim, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* VideoPose3D TemporalModel lifter  (VideoPose3D/common/model.py:79-138)     */
+/* ------------------------------------------------------------------------- */
+typedef struct skimi_vp3d skimi_vp3d;
+
+/* filter_widths: e.g. {3,3,3}; causal as TemporalModel(causal=...) */
+skimi_vp3d* skimi_vp3d_create(int32_t joints_in, int32_t in_features, int32_t joints_out,
+                              const int32_t* filter_widths, int32_t n_widths,
+                              int32_t channels, int32_t causal);
+void skimi_vp3d_destroy(skimi_vp3d*);
+/* one state_dict entry, by its reference key name ("expand_conv.weight",
+ * "layers_bn.0.running_var", "shrink.bias", ...; VideoPose3D/run.py:288-289).
+ * data is a host fp32 array of n elements (num_batches_tracked is ignored). */
+int skimi_vp3d_set_weight(skimi_vp3d*, const char* key, const float* host_data, int64_t n);
+/* fold BatchNorm (eval mode, model.py:127,134-135) into conv weight + bias, repack
+ * [Cout,Cin,k] -> [Cout,k,Cin], upload.  prec selects the MFMA mode. */
+int skimi_vp3d_finalize(skimi_vp3d*, int32_t prec);
+int32_t skimi_vp3d_receptive_field(const skimi_vp3d*);   /* model.py:41-48 */
+size_t skimi_vp3d_workspace_bytes(const skimi_vp3d*, int32_t batch, int32_t frames_in);
+/* x: dev f32 [batch, frames_in, joints_in, in_features]; out: dev f32
+ * [batch, frames_in - rf + 1, joints_out, 3]  (model.py:63-77) */
+int skimi_vp3d_forward(skimi_vp3d*, const float* x, float* out, int32_t batch, int32_t frames_in,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKIMI_H */

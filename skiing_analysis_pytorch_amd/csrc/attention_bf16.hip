@@ -1,0 +1,257 @@
+// bf16 flash attention for head_dim 64 on gfx950 MFMA (v_mfma_f32_32x32x16_bf16), fp32 softmax.
+// The MFMA-roofline kernel of the path: frame attention (batch = S frames, seq 1374) and global
+// attention (batch = 1, seq = S*1374) of vggt/vggt/models/aggregator.py:260-305 via
+// F.scaled_dot_product_attention (vggt/vggt/layers/attention.py:60-61), and the 24 DINOv2 blocks.
+//
+// Per workgroup: 4 waves x 32 queries; K/V tiles of 64 keys double-buffered in LDS, staged
+// global -> VGPR -> LDS (issue before the MFMA phase, write after it), one barrier per tile.
+// Products are "swapped" so each softmax row is lane-local:
+//   S^T[key, q] = K Q^T   A = K from LDS (ds_read_b128, XOR-swizzled rows), B = Q from registers
+//   O^T[d, q]  += V^T P^T A = V^T from LDS via ds_read_b64_tr_b16 (hardware transpose of a
+//                          row-major [key][d] tile), B = P: the S^T accumulator converted to bf16
+//                          in place (k order inside a step: key = 16s + 8(j>>2) + 4h + (j&3)).
+// blockIdx -> (batch, head, q-block) is XCD-contiguous so one XCD's L2 holds a head's K/V.
+#include "common.h"
+#include "kernels.h"
+
+namespace skimi {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& p, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(p[8 * s + j]);
+    return r;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a, int nqb) {
+    constexpr int KV = 64;                 // keys per tile
+    constexpr int TILE = KV * 64 * 2;      // bytes of one K (or V) tile
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [buf][K|V]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-contiguous remap of the 1-D grid
+    int id;
+    {
+        const int nblk = gridDim.x;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7;
+        const int q = nblk >> 3, r = nblk & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int qb = id % nqb;
+    const int bh = id / nqb;
+    const int head = bh % a.heads, b = bh / a.heads;
+    const int q0 = qb * 128 + wave * 32;
+
+    const unsigned short* Q = (const unsigned short*)a.q + (long)b * a.q_batch + (long)head * a.q_head;
+    const unsigned short* K = (const unsigned short*)a.k + (long)b * a.k_batch + (long)head * a.k_head;
+    const unsigned short* V = (const unsigned short*)a.v + (long)b * a.v_batch + (long)head * a.v_head;
+    unsigned short* O = (unsigned short*)a.out + (long)b * a.o_batch + (long)head * a.o_head;
+
+    // Q fragments (B operand): lane (q, h) holds Q[q][16s + 8h + j]
+    bf16x8 qf[4];
+    {
+        const int q = min(q0 + l31, a.seq_q - 1);
+        const unsigned short* qp = Q + (long)q * a.q_row + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+    }
+
+    // staging coordinates: 2 x 16-B chunks of K and of V per thread
+    int st_r[2], st_c[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = i * 256 + tid;
+        st_r[i] = c >> 3;
+        st_c[i] = c & 7;
+    }
+    bf16x8 kreg[2], vreg[2];
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = kt * KV + st_r[i];
+            if (key < a.seq_k) {
+                kreg[i] = *reinterpret_cast<const bf16x8*>(K + (long)key * a.k_row + st_c[i] * 8);
+                vreg[i] = *reinterpret_cast<const bf16x8*>(V + (long)key * a.v_row + st_c[i] * 8);
+            } else {
+                kreg[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                vreg[i] = kreg[i];
+            }
+        }
+    };
+    // K rows: chunk ^= (row>>1)&7  (conflict-free ds_read_b128 of 32 rows at one chunk)
+    // V rows: chunk ^= ((row>>1)&1)<<2 (conflict-free ds_read_b64_tr_b16 of 4-row blocks)
+    auto write = [&](int buf) {
+        char* kb = smem + buf * 2 * TILE;
+        char* vb = kb + TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = st_r[i], c = st_c[i];
+            *reinterpret_cast<bf16x8*>(kb + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kreg[i];
+            *reinterpret_cast<bf16x8*>(vb + r * 128 + ((c ^ (((r >> 1) & 1) << 2)) << 4)) = vreg[i];
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+    const float c2 = a.scale * 1.44269504088896340736f;   // softmax scale folded into exp2
+
+    const int nkt = (a.seq_k + KV - 1) / KV;
+    issue(0);
+    write(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) issue(kt + 1);
+        const char* kb = smem + cur * 2 * TILE;
+        const char* vb = kb + TILE;
+
+        // ---- S^T = K Q^T : two 32-key sub-tiles ----
+        f32x16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            const int row = t * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf =
+                    *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+            }
+        }
+        // mask keys past the end (last tile only)
+        if (kt == nkt - 1 && (a.seq_k & (KV - 1)) != 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * KV + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= a.seq_k) s[t][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (row = query = this lane, both halves) ----
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[t][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(m, mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c2);
+        const float mb = mnew * c2;
+        m = mnew;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[t][r] = __builtin_amdgcn_exp2f(s[t][r] * c2 - mb);
+                psum += s[t][r];
+            }
+        lsum = lsum * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 pf = pack8(s[t], ks);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    // tr-read block: rows key0 + q (q = (lane&15)>>2), cols dcol0 + 4p (p = lane&3)
+                    const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+                    const int dcol = dt * 32 + 16 * ((lane >> 4) & 1) + 4 * p4;   // first of 4 d columns
+                    bf16x8 vf;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int row = t * 32 + 16 * ks + 8 * half + 4 * lh + q4;
+                        const int chunk = (dcol >> 3) ^ (((row >> 1) & 1) << 2);
+                        const char* addr = vb + row * 128 + (chunk << 4) + ((dcol & 7) << 1);
+                        const s16x4 v4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)addr);
+                        vf[4 * half + 0] = v4[0];
+                        vf[4 * half + 1] = v4[1];
+                        vf[4 * half + 2] = v4[2];
+                        vf[4 * half + 3] = v4[3];
+                    }
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+
+        if (kt + 1 < nkt) write(cur ^ 1);
+        __syncthreads();
+    }
+
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.f / lsum;
+    const int q = q0 + l31;
+    if (q < a.seq_q) {
+        unsigned short* op = O + (long)q * a.o_row;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (short)f2bf(o[dt][4 * g + j] * inv);
+                *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g + 4 * lh) = v;
+            }
+    }
+}
+
+int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
+    SKIMI_CHECK_ARG(a.q && a.k && a.v && a.out, "skimi_attention: null buffer");
+    SKIMI_CHECK_ARG(a.batch > 0 && a.heads > 0 && a.seq_q > 0 && a.seq_k > 0, "skimi_attention: empty shape");
+    SKIMI_CHECK_ARG(a.head_dim == 64, "skimi_attention: the bf16 MFMA kernel is head_dim 64 only (got %d)", a.head_dim);
+    SKIMI_CHECK_ARG(a.q_row % 8 == 0 && a.k_row % 8 == 0 && a.v_row % 8 == 0 && a.o_row % 4 == 0 &&
+                    a.q_head % 8 == 0 && a.k_head % 8 == 0 && a.v_head % 8 == 0 && a.o_head % 4 == 0 &&
+                    a.q_batch % 8 == 0 && a.k_batch % 8 == 0 && a.v_batch % 8 == 0 && a.o_batch % 4 == 0,
+                    "skimi_attention: bf16 strides must keep 16-B alignment");
+    const int nqb = (int)cdiv(a.seq_q, 128);
+    const long nblk = (long)nqb * a.heads * a.batch;
+    SKIMI_CHECK_ARG(nblk < (1l << 31), "skimi_attention: grid too large");
+    hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb);
+    SKIMI_LAUNCH_CHECK();
+    return SKIMI_OK;
+}
+
+int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
+                     hipStream_t st) {
+    SKIMI_CHECK_ARG(qkv && out, "skimi_attention: null buffer");
+    AttnArgs a;
+    const long C = (long)heads * head_dim;
+    const size_t es = dtype == SKIMI_F32 ? 4 : 2;
+    a.q = qkv;
+    a.k = (const char*)qkv + C * es;
+    a.v = (const char*)qkv + 2 * C * es;
+    a.out = out;
+    a.q_row = a.k_row = a.v_row = 3 * C;
+    a.o_row = C;
+    a.q_batch = a.k_batch = a.v_batch = (long)seq * 3 * C;
+    a.o_batch = (long)seq * C;
+    a.q_head = a.k_head = a.v_head = a.o_head = head_dim;
+    a.batch = batch;
+    a.heads = heads;
+    a.seq_q = a.seq_k = seq;
+    a.head_dim = head_dim;
+    a.scale = 1.0f / sqrtf((float)head_dim);
+    if (dtype == SKIMI_F32) return attention_f32_launch(a, st);
+    return attention_bf16_launch(a, st);
+}
+
+}  // namespace skimi

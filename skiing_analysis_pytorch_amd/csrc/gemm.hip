@@ -1,0 +1,591 @@
+// Fused MFMA contraction for gfx950:  out = epilogue( gather(A) . W^T )
+//
+// One kernel template serves every Linear / Conv1d / Conv2d / ConvTranspose2d(k==s) on
+// the hot path (reference: vggt/vggt/layers/{attention,mlp,patch_embed}.py,
+// vggt/vggt/heads/dpt_head.py, VideoPose3D/common/model.py:126-138):
+//   * A is channels-last; "plain" rows or an implicit-im2col gather of a KHxKW window
+//     (tap-major K), so a 3x3 conv is 9 shifted GEMM-accumulates with no im2col buffer;
+//   * W is [N, K] (nn.Linear layout; conv weights are repacked [Cout, ky, kx, Cin] once);
+//   * 128x128 (or 64x64) output tile per 256-thread workgroup, 4 waves as 2x2, each wave
+//     a 2x2 (1x1) grid of v_mfma_f32_32x32x16_bf16 tiles, fp32 accumulate;
+//   * operands staged global -> VGPR -> LDS (issue early, write after the MFMA phase),
+//     two LDS buffers, one barrier per K-tile; LDS rows XOR-swizzled per 16-B chunk so the
+//     ds_read_b128 fragment reads are bank-conflict free;
+//   * PREC_BF16X3 keeps fp32 operands in HBM and splits them hi+lo while staging:
+//     acc += Ahi*Whi + Ahi*Wlo + Alo*Whi  (three MFMAs per k-step, ~fp32 operand accuracy);
+//   * split-K (grid.y) accumulates fp32 partials with global atomics into a zeroed slab and
+//     a second small kernel applies the epilogue — used when M is too small to fill 256 CUs;
+//   * blockIdx -> tile map is XCD-aware: each XCD walks a contiguous run of tiles that share
+//     an A row panel, so the panel and W stay in that XCD's L2.
+#include "common.h"
+#include <algorithm>
+
+namespace skimi {
+
+struct GemmArgs {
+    int M, N, K;
+    const void* A;
+    const void* W;
+    long lda, ldw;
+    int a_mode;
+    int cN, cH, cW, cC, KH, KW, stride, pad, dil, OH, OW;
+    const float* bias;
+    const float* gamma;
+    const float* resid;
+    long ldr;
+    int resid_rpb;
+    long resid_bs;
+    long resid_off;
+    int act;
+    void* out;
+    void* out2;
+    int out_dtype;
+    long ldo, ldo2;
+    int store_mode, ps_s, ps_C;
+    // split-K
+    int splitk;
+    int k_per_split;   // multiple of BK
+    float* partial;    // [M, N] fp32, zeroed
+    int ntm, ntn;
+    int vec4;          // epilogue may use 16-B accesses (N, ld*, pointers all 4-element aligned)
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case SKIMI_ACT_RELU: return fmaxf(v, 0.f);
+        case SKIMI_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case SKIMI_ACT_SILU: return v / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+// everything that depends only on the output row m
+struct RowMap {
+    long out_off;   // mode 0: m*ldo; mode 1: top-left output pixel index of this input pixel
+    long out2_off;  // same for out2
+    long res_off;
+};
+
+__device__ __forceinline__ RowMap row_map(const GemmArgs& p, int m) {
+    RowMap r;
+    if (p.store_mode == 0) {
+        r.out_off = (long)m * p.ldo;
+        r.out2_off = (long)m * p.ldo2;
+    } else {
+        // m = (img, iy, ix) over [cN, cH, cW]
+        int hw = p.cH * p.cW;
+        int img = m / hw;
+        int rem = m - img * hw;
+        int iy = rem / p.cW;
+        int ix = rem - iy * p.cW;
+        long OWs = (long)p.cW * p.ps_s;
+        r.out_off = (((long)img * p.cH * p.ps_s + (long)iy * p.ps_s) * OWs + (long)ix * p.ps_s);
+        r.out2_off = r.out_off;
+    }
+    long mr = m;
+    if (p.resid_rpb > 0) {
+        int b = m / p.resid_rpb;
+        mr = (long)b * p.resid_bs + (m - b * p.resid_rpb);
+    }
+    r.res_off = (mr + p.resid_off) * p.ldr;
+    return r;
+}
+
+__device__ __forceinline__ void store_one(const GemmArgs& p, const RowMap& rm, int n, float acc) {
+    float v = acc;
+    if (p.bias) v += p.bias[n];
+    v = apply_act(v, p.act);
+    if (p.gamma) v *= p.gamma[n];
+    if (p.resid) v += p.resid[rm.res_off + n];
+    long o, o2;
+    if (p.store_mode == 0) {
+        o = rm.out_off + n;
+        o2 = rm.out2_off + n;
+    } else {
+        int ab = n / p.ps_C;
+        int co = n - ab * p.ps_C;
+        int a = ab / p.ps_s;
+        int b = ab - a * p.ps_s;
+        long OWs = (long)p.cW * p.ps_s;
+        long pix = rm.out_off + (long)a * OWs + b;
+        o = pix * p.ldo + co;
+        o2 = pix * p.ldo2 + co;
+    }
+    if (p.out_dtype == SKIMI_F32) {
+        ((float*)p.out)[o] = v;
+        if (p.out2) ((unsigned short*)p.out2)[o2] = f2bf(v);
+    } else {
+        ((unsigned short*)p.out)[o] = f2bf(v);
+        if (p.out2) ((float*)p.out2)[o2] = v;
+    }
+}
+
+// four consecutive columns n..n+3 of one row (vectorised epilogue)
+__device__ __forceinline__ void store_four(const GemmArgs& p, const RowMap& rm, int n, float4 acc) {
+    float v[4] = {acc.x, acc.y, acc.z, acc.w};
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], p.act);
+    if (p.gamma) {
+        const float4 g = *reinterpret_cast<const float4*>(p.gamma + n);
+        v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+    }
+    if (p.resid) {
+        const float4 r = *reinterpret_cast<const float4*>(p.resid + rm.res_off + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    long o, o2;
+    if (p.store_mode == 0) {
+        o = rm.out_off + n;
+        o2 = rm.out2_off + n;
+    } else {
+        int ab = n / p.ps_C;
+        int co = n - ab * p.ps_C;
+        int a = ab / p.ps_s;
+        int b = ab - a * p.ps_s;
+        long OWs = (long)p.cW * p.ps_s;
+        long pix = rm.out_off + (long)a * OWs + b;
+        o = pix * p.ldo + co;
+        o2 = pix * p.ldo2 + co;
+    }
+    bf16x4 hb;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hb[k] = (short)f2bf(v[k]);
+    const float4 fv = make_float4(v[0], v[1], v[2], v[3]);
+    if (p.out_dtype == SKIMI_F32) {
+        *reinterpret_cast<float4*>((float*)p.out + o) = fv;
+        if (p.out2) *reinterpret_cast<bf16x4*>((unsigned short*)p.out2 + o2) = hb;
+    } else {
+        *reinterpret_cast<bf16x4*>((unsigned short*)p.out + o) = hb;
+        if (p.out2) *reinterpret_cast<float4*>((float*)p.out2 + o2) = fv;
+    }
+}
+
+// ---- staging helpers ------------------------------------------------------------------
+template <typename T> struct Stage;
+template <> struct Stage<float> { float4 a, b; };
+template <> struct Stage<unsigned short> { bf16x8 v; };
+
+__device__ __forceinline__ void stage_load(Stage<float>& s, const float* p, bool ok) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    s.a = ok ? *reinterpret_cast<const float4*>(p) : z;
+    s.b = ok ? *reinterpret_cast<const float4*>(p + 4) : z;
+}
+__device__ __forceinline__ void stage_load(Stage<unsigned short>& s, const unsigned short* p, bool ok) {
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    s.v = ok ? *reinterpret_cast<const bf16x8*>(p) : z;
+}
+__device__ __forceinline__ void split1(float x, short& hi, short& lo) {
+    const unsigned short h = f2bf(x);
+    hi = (short)h;
+    lo = (short)f2bf(x - bf2f(h));
+}
+__device__ __forceinline__ void stage_split(const Stage<float>& s, bf16x8& hi, bf16x8& lo) {
+    short h, l;
+    split1(s.a.x, h, l); hi[0] = h; lo[0] = l;
+    split1(s.a.y, h, l); hi[1] = h; lo[1] = l;
+    split1(s.a.z, h, l); hi[2] = h; lo[2] = l;
+    split1(s.a.w, h, l); hi[3] = h; lo[3] = l;
+    split1(s.b.x, h, l); hi[4] = h; lo[4] = l;
+    split1(s.b.y, h, l); hi[5] = h; lo[5] = l;
+    split1(s.b.z, h, l); hi[6] = h; lo[6] = l;
+    split1(s.b.w, h, l); hi[7] = h; lo[7] = l;
+}
+__device__ __forceinline__ void stage_split(const Stage<unsigned short>& s, bf16x8& hi, bf16x8& lo) {
+    hi = s.v;
+    lo = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+}
+__device__ __forceinline__ bf16x8 stage_round(const Stage<float>& s) {
+    bf16x8 r;
+    r[0] = (short)f2bf(s.a.x); r[1] = (short)f2bf(s.a.y); r[2] = (short)f2bf(s.a.z); r[3] = (short)f2bf(s.a.w);
+    r[4] = (short)f2bf(s.b.x); r[5] = (short)f2bf(s.b.y); r[6] = (short)f2bf(s.b.z); r[7] = (short)f2bf(s.b.w);
+    return r;
+}
+__device__ __forceinline__ bf16x8 stage_round(const Stage<unsigned short>& s) { return s.v; }
+
+template <int BM, int BN, int BK, int NSPLIT, typename TA, typename TW>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    constexpr int CPR = BK / 8;        // 16-B chunks per LDS row
+    constexpr int RB = BK * 2;         // LDS row bytes
+    constexpr int RPB = 256 / RB;      // LDS rows per 256-B bank row
+    constexpr int A_IT = BM * CPR / 256;
+    constexpr int W_IT = BN * CPR / 256;
+    constexpr int NPL = (NSPLIT == 3) ? 2 : 1;   // planes per operand (hi, lo)
+    constexpr int A_PLANE = BM * RB;
+    constexpr int W_PLANE = BN * RB;
+    constexpr int BUF = NPL * (A_PLANE + W_PLANE);
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // XCD-aware, bijective blockIdx -> tile id (blocks b and b+8 share an XCD)
+    int id;
+    {
+        const int nblk = p.ntm * p.ntn;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7;
+        const int q = nblk >> 3, r = nblk & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = id / p.ntn, tn = id - tm * p.ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int kb = blockIdx.y * p.k_per_split;
+    const int ke = min(p.K, kb + p.k_per_split);
+    const int nkt = (ke - kb + BK - 1) / BK;
+
+    // ---- per-thread staging coordinates ----
+    int a_r[A_IT], a_c[A_IT];
+    bool a_ok[A_IT];
+    long a_base[A_IT];            // plain: row base (elements); conv: image index
+    int a_iy0[A_IT], a_ix0[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        int q = i * 256 + tid;
+        a_r[i] = q / CPR;
+        a_c[i] = q % CPR;
+        int m = m0 + a_r[i];
+        a_ok[i] = m < p.M;
+        if (!a_ok[i]) m = p.M - 1;
+        if (p.a_mode == 0) {
+            a_base[i] = (long)m * p.lda;
+            a_iy0[i] = a_ix0[i] = 0;
+        } else {
+            int ohw = p.OH * p.OW;
+            int img = m / ohw;
+            int rem = m - img * ohw;
+            int oy = rem / p.OW;
+            int ox = rem - oy * p.OW;
+            a_base[i] = img;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+        }
+    }
+    int w_r[W_IT], w_c[W_IT];
+    bool w_ok[W_IT];
+    long w_base[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        int q = i * 256 + tid;
+        w_r[i] = q / CPR;
+        w_c[i] = q % CPR;
+        int n = n0 + w_r[i];
+        w_ok[i] = n < p.N;
+        if (!w_ok[i]) n = p.N - 1;
+        w_base[i] = (long)n * p.ldw;
+    }
+
+    Stage<TA> sa[A_IT];
+    Stage<TW> sw[W_IT];
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lh = lane >> 5;
+
+#define LDS_OFF(r, c) ((r) * RB + ((((c) ^ (((r) / RPB) % CPR))) << 4))
+
+    // software pipeline, each stage written once: iteration kt issues the global loads of tile
+    // kt+1, runs the MFMAs of tile kt from LDS, then parks tile kt+1 in the other LDS buffer.
+    for (int kt = -1; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) {
+            // ---- issue global loads of tile kt+1 into registers ----
+            const int k0 = kb + (kt + 1) * BK;
+            int tap_dy = 0, tap_dx = 0, cin0 = k0;
+            if (p.a_mode != 0) {
+                int tap = k0 / p.cC;
+                cin0 = k0 - tap * p.cC;
+                int ky = tap / p.KW;
+                int kx = tap - ky * p.KW;
+                tap_dy = ky * p.dil;
+                tap_dx = kx * p.dil;
+            }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int kk = k0 + a_c[i] * 8;
+                bool ok = a_ok[i] && kk < ke;
+                long off;
+                if (p.a_mode == 0) {
+                    off = a_base[i] + kk;
+                } else {
+                    int iy = a_iy0[i] + tap_dy, ix = a_ix0[i] + tap_dx;
+                    ok = ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
+                    off = ((a_base[i] * p.cH + iy) * p.cW + ix) * p.lda + cin0 + a_c[i] * 8;
+                }
+                stage_load(sa[i], reinterpret_cast<const TA*>(p.A) + (ok ? off : 0), ok);
+            }
+#pragma unroll
+            for (int i = 0; i < W_IT; ++i) {
+                const int kk = k0 + w_c[i] * 8;
+                const bool ok = w_ok[i] && kk < ke;
+                stage_load(sw[i], reinterpret_cast<const TW*>(p.W) + (ok ? (w_base[i] + kk) : 0), ok);
+            }
+        }
+        if (kt >= 0) {
+            // ---- MFMAs of tile kt ----
+            const char* ab = smem + (kt & 1) * BUF;
+            const char* wb = ab + NPL * A_PLANE;
+#pragma unroll
+            for (int s = 0; s < BK / 16; ++s) {
+                bf16x8 a_hi[MT], w_hi[NT], a_lo[MT], w_lo[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = wr * WM + i * 32 + l31;
+                    const int o = LDS_OFF(row, 2 * s + lh);
+                    a_hi[i] = *reinterpret_cast<const bf16x8*>(ab + o);
+                    if (NSPLIT == 3) a_lo[i] = *reinterpret_cast<const bf16x8*>(ab + A_PLANE + o);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int row = wc * WN + j * 32 + l31;
+                    const int o = LDS_OFF(row, 2 * s + lh);
+                    w_hi[j] = *reinterpret_cast<const bf16x8*>(wb + o);
+                    if (NSPLIT == 3) w_lo[j] = *reinterpret_cast<const bf16x8*>(wb + W_PLANE + o);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        if (NSPLIT == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], w_hi[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], w_lo[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], w_hi[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        if (more) {
+            // ---- park tile kt+1 in LDS ----
+            char* base = smem + ((kt + 1) & 1) * BUF;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int o = LDS_OFF(a_r[i], a_c[i]);
+                if (NSPLIT == 3) {
+                    bf16x8 hi, lo;
+                    stage_split(sa[i], hi, lo);
+                    *reinterpret_cast<bf16x8*>(base + o) = hi;
+                    *reinterpret_cast<bf16x8*>(base + A_PLANE + o) = lo;
+                } else {
+                    *reinterpret_cast<bf16x8*>(base + o) = stage_round(sa[i]);
+                }
+            }
+            char* wbw = base + NPL * A_PLANE;
+#pragma unroll
+            for (int i = 0; i < W_IT; ++i) {
+                const int o = LDS_OFF(w_r[i], w_c[i]);
+                if (NSPLIT == 3) {
+                    bf16x8 hi, lo;
+                    stage_split(sw[i], hi, lo);
+                    *reinterpret_cast<bf16x8*>(wbw + o) = hi;
+                    *reinterpret_cast<bf16x8*>(wbw + W_PLANE + o) = lo;
+                } else {
+                    *reinterpret_cast<bf16x8*>(wbw + o) = stage_round(sw[i]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef LDS_OFF
+
+    // ---- epilogue: accumulators -> per-wave LDS tile -> row-contiguous 16-B stores ----
+    // (the K loop ended on a barrier, so the staging buffers are free)
+    float* stg = reinterpret_cast<float*>(smem) + wave * (WM * WN);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stg[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * WN + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    constexpr int LPR = WN / 4;          // lanes per row
+    constexpr int RPI = 64 / LPR;        // rows per wave-instruction
+    const int col_l = 4 * (lane % LPR);
+    const int n = n0 + wc * WN + col_l;
+#pragma unroll 1
+    for (int it = 0; it < WM / RPI; ++it) {
+        const int row_l = it * RPI + lane / LPR;
+        const int m = m0 + wr * WM + row_l;
+        if (m >= p.M || n >= p.N) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&stg[row_l * WN + col_l]);
+        if (p.splitk > 1) {
+            float* dst = p.partial + (long)m * p.N + n;
+            atomicAdd(dst, v.x);
+            if (n + 1 < p.N) atomicAdd(dst + 1, v.y);
+            if (n + 2 < p.N) atomicAdd(dst + 2, v.z);
+            if (n + 3 < p.N) atomicAdd(dst + 3, v.w);
+        } else {
+            const RowMap rm = row_map(p, m);
+            if (p.vec4) {
+                store_four(p, rm, n, v);
+            } else {
+                store_one(p, rm, n, v.x);
+                if (n + 1 < p.N) store_one(p, rm, n + 1, v.y);
+                if (n + 2 < p.N) store_one(p, rm, n + 2, v.z);
+                if (n + 3 < p.N) store_one(p, rm, n + 3, v.w);
+            }
+        }
+    }
+}
+
+// second pass of a split-K launch: partial[M,N] -> epilogue -> out
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue(const GemmArgs p) {
+    const long total = (long)p.M * p.N;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int m = (int)(idx / p.N);
+        const int n = (int)(idx - (long)m * p.N);
+        const RowMap rm = row_map(p, m);
+        store_one(p, rm, n, p.partial[idx]);
+    }
+}
+
+template <int BM, int BN, int BK, int NSPLIT, typename TA, typename TW>
+static int launch_cfg(const GemmArgs& a, hipStream_t st) {
+    constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
+    constexpr size_t lds = 2ull * NPL * (BM + BN) * BK * 2;
+    auto kfn = gemm_kernel<BM, BN, BK, NSPLIT, TA, TW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return SKIMI_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    dim3 grid(a.ntm * a.ntn, a.splitk);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    SKIMI_LAUNCH_CHECK();
+    return SKIMI_OK;
+}
+
+// scratch: caller-owned fp32 slab [M, N] for split-K partials (NULL => split-K is not used)
+int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_t scratch_bytes,
+                  int force_splitk) {
+    SKIMI_CHECK_ARG(d != nullptr, "skimi_gemm: null descriptor");
+    SKIMI_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "skimi_gemm: empty shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    SKIMI_CHECK_ARG(d->K % 8 == 0, "skimi_gemm: K=%d must be a multiple of 8", d->K);
+    SKIMI_CHECK_ARG(d->A && d->W && d->out, "skimi_gemm: null buffer");
+    SKIMI_CHECK_ARG(d->lda % 4 == 0 && d->ldw % 8 == 0 && d->lda >= 0,
+                    "skimi_gemm: lda/ldw must keep 16-B alignment (lda=%ld ldw=%ld)", (long)d->lda, (long)d->ldw);
+    SKIMI_CHECK_ARG(!(d->a_dtype == SKIMI_BF16 && d->lda % 8 != 0), "skimi_gemm: bf16 lda must be a multiple of 8");
+    SKIMI_CHECK_ARG(d->prec == SKIMI_PREC_BF16 || d->prec == SKIMI_PREC_BF16X3, "skimi_gemm: bad prec %d", d->prec);
+    const int BK = d->prec == SKIMI_PREC_BF16 ? 64 : 32;
+    if (d->a_mode != 0) {
+        SKIMI_CHECK_ARG(d->cC % BK == 0, "skimi_gemm: conv gather needs cC %% %d == 0 (cC=%d)", BK, d->cC);
+        SKIMI_CHECK_ARG(d->K == d->KH * d->KW * d->cC, "skimi_gemm: K != KH*KW*cC");
+        SKIMI_CHECK_ARG((long)d->cN * d->OH * d->OW == d->M, "skimi_gemm: M != cN*OH*OW");
+        SKIMI_CHECK_ARG((d->OH - 1) * d->stride - d->pad + (d->KH - 1) * d->dil < d->cH + d->pad &&
+                        (d->OW - 1) * d->stride - d->pad + (d->KW - 1) * d->dil < d->cW + d->pad,
+                        "skimi_gemm: conv window exceeds padded input");
+        SKIMI_CHECK_ARG(d->lda >= d->cC, "skimi_gemm: conv pixel stride lda < cC");
+    }
+    if (d->store_mode == 1) {
+        SKIMI_CHECK_ARG(d->ps_s > 0 && d->ps_C > 0 && d->N == d->ps_s * d->ps_s * d->ps_C &&
+                        (long)d->cN * d->cH * d->cW == d->M, "skimi_gemm: bad pixel-shuffle store geometry");
+    }
+    if (d->resid) SKIMI_CHECK_ARG(d->ldr >= d->N, "skimi_gemm: ldr < N");
+
+    GemmArgs a;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.A = d->A; a.W = d->W; a.lda = d->lda; a.ldw = d->ldw;
+    a.a_mode = d->a_mode;
+    a.cN = d->cN; a.cH = d->cH; a.cW = d->cW; a.cC = d->cC; a.KH = d->KH; a.KW = d->KW;
+    a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.OH = d->OH; a.OW = d->OW;
+    a.bias = d->bias; a.gamma = d->gamma; a.resid = d->resid; a.ldr = d->ldr;
+    a.resid_rpb = d->resid_rows_per_batch; a.resid_bs = d->resid_batch_stride; a.resid_off = d->resid_row_off;
+    a.act = d->act;
+    a.out = d->out; a.out2 = d->out2; a.out_dtype = d->out_dtype; a.ldo = d->ldo; a.ldo2 = d->ldo2;
+    a.store_mode = d->store_mode; a.ps_s = d->ps_s; a.ps_C = d->ps_C;
+    a.partial = nullptr;
+    {
+        auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+        const bool out_ok = d->out_dtype == SKIMI_F32 ? al16(d->out) : (((uintptr_t)d->out & 7) == 0);
+        const bool out2_ok = !d->out2 || (d->out_dtype == SKIMI_F32 ? (((uintptr_t)d->out2 & 7) == 0) : al16(d->out2));
+        a.vec4 = (d->N % 4 == 0) && (d->ldo % 4 == 0) && (!d->out2 || d->ldo2 % 4 == 0) && out_ok && out2_ok &&
+                 (!d->bias || al16(d->bias)) && (!d->gamma || al16(d->gamma)) &&
+                 (!d->resid || (al16(d->resid) && d->ldr % 4 == 0)) && (d->store_mode == 0 || d->ps_C % 4 == 0);
+    }
+
+    // tile + split-K choice: fill >= ~256 CUs
+    const long t128 = cdiv(d->M, 128) * cdiv(d->N, 128);
+    const bool small = t128 < 128;
+    const int BM = small ? 64 : 128;
+    a.ntm = (int)cdiv(d->M, BM);
+    a.ntn = (int)cdiv(d->N, BM);
+    const long tiles = (long)a.ntm * a.ntn;
+    int splitk = 1;
+    const int nkt = (int)cdiv(d->K, BK);
+    if (force_splitk > 0) {
+        splitk = force_splitk;
+    } else if (tiles < 192 && nkt >= 8 && scratch != nullptr &&
+               (size_t)d->M * d->N * sizeof(float) <= scratch_bytes) {
+        splitk = (int)std::min<long>(cdiv(512, tiles), nkt / 4);
+        if (splitk < 1) splitk = 1;
+    }
+    int kper = (int)cdiv(nkt, splitk) * BK;
+    splitk = (int)cdiv(d->K, kper);
+    a.splitk = splitk;
+    a.k_per_split = kper;
+    if (splitk > 1) {
+        size_t need = (size_t)d->M * d->N * sizeof(float);
+        if (scratch == nullptr || need > scratch_bytes) {
+            set_error("skimi_gemm: split-K scratch too small (%zu needed, %zu given)", need, scratch_bytes);
+            return SKIMI_ERR_WORKSPACE;
+        }
+        a.partial = (float*)scratch;
+        SKIMI_HIP(hipMemsetAsync(scratch, 0, need, st));
+    }
+
+    int rc;
+    const bool af = d->a_dtype == SKIMI_F32, wf = d->w_dtype == SKIMI_F32;
+#define SKIMI_GO(BM_, BK_, NS_, TA_, TW_) rc = launch_cfg<BM_, BM_, BK_, NS_, TA_, TW_>(a, st)
+    if (d->prec == SKIMI_PREC_BF16) {
+        if (BM == 128) {
+            if (af && wf) SKIMI_GO(128, 64, 1, float, float);
+            else if (af) SKIMI_GO(128, 64, 1, float, unsigned short);
+            else if (wf) SKIMI_GO(128, 64, 1, unsigned short, float);
+            else SKIMI_GO(128, 64, 1, unsigned short, unsigned short);
+        } else {
+            if (af && wf) SKIMI_GO(64, 64, 1, float, float);
+            else if (af) SKIMI_GO(64, 64, 1, float, unsigned short);
+            else if (wf) SKIMI_GO(64, 64, 1, unsigned short, float);
+            else SKIMI_GO(64, 64, 1, unsigned short, unsigned short);
+        }
+    } else {
+        SKIMI_CHECK_ARG(wf, "skimi_gemm: BF16X3 needs fp32 weights");
+        if (BM == 128) {
+            if (af) SKIMI_GO(128, 32, 3, float, float);
+            else SKIMI_GO(128, 32, 3, unsigned short, float);
+        } else {
+            if (af) SKIMI_GO(64, 32, 3, float, float);
+            else SKIMI_GO(64, 32, 3, unsigned short, float);
+        }
+    }
+#undef SKIMI_GO
+    if (rc != SKIMI_OK) return rc;
+    if (splitk > 1) {
+        long total = (long)d->M * d->N;
+        int blocks = (int)std::min<long>(cdiv(total, 256), 2048);
+        hipLaunchKernelGGL(gemm_splitk_epilogue, dim3(blocks), dim3(256), 0, st, a);
+        SKIMI_LAUNCH_CHECK();
+    }
+    return SKIMI_OK;
+}
+
+}  // namespace skimi

@@ -1,0 +1,39 @@
+// Internal launch entry points shared between translation units of libskimi.
+#pragma once
+#include "common.h"
+
+namespace skimi {
+
+int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_t scratch_bytes,
+                  int force_splitk);
+
+int layernorm_launch(const float* x, const float* x2, int64_t ldx, int64_t rows, int C,
+                     const float* gamma, const float* beta, float eps, void* out, int out_dtype,
+                     int64_t ldo, hipStream_t st);
+
+int qknorm_rope_launch(void* qkv, int dtype, int64_t tokens, int heads, const float* qn_w,
+                       const float* qn_b, const float* kn_w, const float* kn_b, float eps,
+                       const int32_t* pos, const float* rope_cos, const float* rope_sin, int rope_npos,
+                       hipStream_t st);
+
+// general attention: q rows [batch, seq_q], k/v rows [batch, seq_k]; element strides
+struct AttnArgs {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* out;
+    long q_row, k_row, v_row, o_row;        // stride between consecutive tokens
+    long q_batch, k_batch, v_batch, o_batch;  // stride between batches
+    long q_head, k_head, v_head, o_head;    // stride between heads
+    int batch, heads, seq_q, seq_k, head_dim;
+    float scale;
+};
+int attention_f32_launch(const AttnArgs& a, hipStream_t st);
+int attention_bf16_launch(const AttnArgs& a, hipStream_t st);
+int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
+                     hipStream_t st);
+
+// VideoPose3D expand-conv im2col: x [B, L, Cin] f32 -> A0 [B*(L-k+1), Kpad] f32 (zero padded)
+int vp3d_im2col_launch(const float* x, float* a0, int B, int L, int Cin, int k, int Kpad, hipStream_t st);
+
+}  // namespace skimi

@@ -1,0 +1,312 @@
+// VideoPose3D TemporalModel forward (VideoPose3D/common/model.py:79-138) as a chain of fused
+// MFMA contractions on channels-last activations [B, L, C]:
+//   expand_conv(k) -> BN -> ReLU                    one GEMM over zero-padded windows (im2col of 34 ch)
+//   per block i: conv(k, dilation 3^i) -> BN -> ReLU  implicit-gather GEMM, K = k*C (tap-major)
+//                conv1x1 -> BN -> ReLU, + res         GEMM with the residual slice fused in the epilogue
+//   shrink (1x1, bias)                              GEMM N = joints_out*3
+// Eval-mode BatchNorm is affine, so it is folded into the conv weight and bias once at finalize
+// (model.py:127,134-135); dropout is identity in eval.  Activations stay fp32 in HBM; the MFMA
+// operands are bf16 (PREC_BF16) or split bf16 hi+lo (PREC_BF16X3, ~fp32 accuracy).
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+using namespace skimi;
+
+struct skimi_vp3d {
+    int joints_in, in_features, joints_out, channels, causal;
+    std::vector<int> fw;          // filter widths
+    std::vector<int> pad;         // model.py:31,106
+    std::vector<int> causal_shift;
+    std::vector<int> dilation;    // dilation of block i's first conv (i >= 1)
+    std::map<std::string, std::vector<float>> host;
+    bool finalized = false;
+    int prec = SKIMI_PREC_BF16X3;
+    int k0pad = 0;                // padded K of the expand GEMM
+    // device weights (fp32 or bf16 depending on prec) + fp32 biases
+    void* w_expand = nullptr;
+    float* b_expand = nullptr;
+    std::vector<void*> w_conv;    // 2 per block
+    std::vector<float*> b_conv;
+    void* w_shrink = nullptr;
+    float* b_shrink = nullptr;
+    std::vector<void*> allocs;
+};
+
+static int upload(skimi_vp3d* h, const std::vector<float>& src, bool as_bf16, void** out) {
+    void* d = nullptr;
+    if (as_bf16) {
+        std::vector<unsigned short> tmp(src.size());
+        for (size_t i = 0; i < src.size(); ++i) {
+            // round to nearest even, as the device cast does
+            unsigned int u;
+            memcpy(&u, &src[i], 4);
+            unsigned int r = u + 0x7FFFu + ((u >> 16) & 1u);
+            tmp[i] = (unsigned short)(r >> 16);
+        }
+        SKIMI_HIP(hipMalloc(&d, tmp.size() * 2));
+        SKIMI_HIP(hipMemcpy(d, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        SKIMI_HIP(hipMalloc(&d, src.size() * 4));
+        SKIMI_HIP(hipMemcpy(d, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    }
+    h->allocs.push_back(d);
+    *out = d;
+    return SKIMI_OK;
+}
+
+extern "C" {
+
+skimi_vp3d* skimi_vp3d_create(int32_t joints_in, int32_t in_features, int32_t joints_out,
+                              const int32_t* filter_widths, int32_t n_widths, int32_t channels,
+                              int32_t causal) {
+    if (joints_in <= 0 || in_features <= 0 || joints_out <= 0 || !filter_widths || n_widths <= 0 ||
+        channels <= 0 || channels % 64 != 0) {
+        set_error("skimi_vp3d_create: bad arguments (channels must be a multiple of 64)");
+        return nullptr;
+    }
+    for (int i = 0; i < n_widths; ++i)
+        if (filter_widths[i] % 2 == 0 || filter_widths[i] <= 0) {
+            // model.py:20-21
+            set_error("skimi_vp3d_create: Only odd filter widths are supported");
+            return nullptr;
+        }
+    skimi_vp3d* h = new skimi_vp3d();
+    h->joints_in = joints_in;
+    h->in_features = in_features;
+    h->joints_out = joints_out;
+    h->channels = channels;
+    h->causal = causal;
+    h->fw.assign(filter_widths, filter_widths + n_widths);
+    // model.py:31,105-110
+    h->pad.push_back(h->fw[0] / 2);
+    h->causal_shift.push_back(causal ? h->fw[0] / 2 : 0);
+    h->dilation.push_back(1);
+    int next_dilation = h->fw[0];
+    for (int i = 1; i < n_widths; ++i) {
+        h->pad.push_back((h->fw[i] - 1) * next_dilation / 2);
+        h->causal_shift.push_back(causal ? (h->fw[i] / 2) * next_dilation : 0);
+        h->dilation.push_back(next_dilation);
+        next_dilation *= h->fw[i];
+    }
+    return h;
+}
+
+void skimi_vp3d_destroy(skimi_vp3d* h) {
+    if (!h) return;
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+int skimi_vp3d_set_weight(skimi_vp3d* h, const char* key, const float* host_data, int64_t n) {
+    SKIMI_CHECK_ARG(h && key && host_data && n > 0, "skimi_vp3d_set_weight: bad arguments");
+    h->host[key].assign(host_data, host_data + n);
+    h->finalized = false;
+    return SKIMI_OK;
+}
+
+int32_t skimi_vp3d_receptive_field(const skimi_vp3d* h) {
+    if (!h) return 0;
+    int frames = 0;
+    for (int p : h->pad) frames += p;
+    return 1 + 2 * frames;
+}
+
+static int need(skimi_vp3d* h, const std::string& k, size_t n, const std::vector<float>** out) {
+    auto it = h->host.find(k);
+    if (it == h->host.end()) {
+        set_error("skimi_vp3d_finalize: missing weight '%s'", k.c_str());
+        return SKIMI_ERR_STATE;
+    }
+    if (it->second.size() != n) {
+        set_error("skimi_vp3d_finalize: weight '%s' has %zu elements, expected %zu", k.c_str(),
+                  it->second.size(), n);
+        return SKIMI_ERR_STATE;
+    }
+    *out = &it->second;
+    return SKIMI_OK;
+}
+
+// fold BN(eval) into a conv: W'[co][tap][ci] = W[co][ci][tap]*s[co]; b'[co] = beta - mean*s
+static int fold(skimi_vp3d* h, const std::string& conv, const std::string& bn, int cout, int cin, int k,
+                int kpad, std::vector<float>* w, std::vector<float>* b) {
+    const std::vector<float>*cw, *g, *be, *mu, *var;
+    int rc;
+    if ((rc = need(h, conv + ".weight", (size_t)cout * cin * k, &cw))) return rc;
+    if ((rc = need(h, bn + ".weight", cout, &g))) return rc;
+    if ((rc = need(h, bn + ".bias", cout, &be))) return rc;
+    if ((rc = need(h, bn + ".running_mean", cout, &mu))) return rc;
+    if ((rc = need(h, bn + ".running_var", cout, &var))) return rc;
+    w->assign((size_t)cout * kpad, 0.f);
+    b->assign(cout, 0.f);
+    for (int co = 0; co < cout; ++co) {
+        const float s = (*g)[co] / sqrtf((*var)[co] + 1e-5f);   // BatchNorm1d eps default
+        (*b)[co] = (*be)[co] - (*mu)[co] * s;
+        for (int t = 0; t < k; ++t)
+            for (int ci = 0; ci < cin; ++ci)
+                (*w)[(size_t)co * kpad + (size_t)t * cin + ci] = (*cw)[((size_t)co * cin + ci) * k + t] * s;
+    }
+    return SKIMI_OK;
+}
+
+int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
+    SKIMI_CHECK_ARG(h, "skimi_vp3d_finalize: null handle");
+    SKIMI_CHECK_ARG(prec == SKIMI_PREC_BF16 || prec == SKIMI_PREC_BF16X3, "skimi_vp3d_finalize: bad prec");
+    for (void* p : h->allocs) (void)hipFree(p);
+    h->allocs.clear();
+    h->w_conv.clear();
+    h->b_conv.clear();
+    h->prec = prec;
+    const bool bf = prec == SKIMI_PREC_BF16;
+    const int C = h->channels, cin0 = h->joints_in * h->in_features;
+    std::vector<float> w, b;
+    int rc;
+    h->k0pad = (int)align_up((size_t)h->fw[0] * cin0, 8);
+    if ((rc = fold(h, "expand_conv", "expand_bn", C, cin0, h->fw[0], h->k0pad, &w, &b))) return rc;
+    if ((rc = upload(h, w, bf, &h->w_expand))) return rc;
+    if ((rc = upload(h, b, false, (void**)&h->b_expand))) return rc;
+    for (size_t i = 1; i < h->fw.size(); ++i) {
+        char cn[64], bn[64];
+        void* dw;
+        float* db;
+        snprintf(cn, sizeof cn, "layers_conv.%zu", 2 * (i - 1));
+        snprintf(bn, sizeof bn, "layers_bn.%zu", 2 * (i - 1));
+        if ((rc = fold(h, cn, bn, C, C, h->fw[i], h->fw[i] * C, &w, &b))) return rc;
+        if ((rc = upload(h, w, bf, &dw))) return rc;
+        if ((rc = upload(h, b, false, (void**)&db))) return rc;
+        h->w_conv.push_back(dw);
+        h->b_conv.push_back(db);
+        snprintf(cn, sizeof cn, "layers_conv.%zu", 2 * (i - 1) + 1);
+        snprintf(bn, sizeof bn, "layers_bn.%zu", 2 * (i - 1) + 1);
+        if ((rc = fold(h, cn, bn, C, C, 1, C, &w, &b))) return rc;
+        if ((rc = upload(h, w, bf, &dw))) return rc;
+        if ((rc = upload(h, b, false, (void**)&db))) return rc;
+        h->w_conv.push_back(dw);
+        h->b_conv.push_back(db);
+    }
+    const std::vector<float>*sw, *sb;
+    const int nout = h->joints_out * 3;
+    if ((rc = need(h, "shrink.weight", (size_t)nout * C, &sw))) return rc;
+    if ((rc = need(h, "shrink.bias", nout, &sb))) return rc;
+    if ((rc = upload(h, *sw, bf, &h->w_shrink))) return rc;
+    if ((rc = upload(h, *sb, false, (void**)&h->b_shrink))) return rc;
+    h->finalized = true;
+    return SKIMI_OK;
+}
+
+// workspace = A0 [B*L0, k0pad] + three activation buffers [B*L0, C] + split-K slab [B*L0, C]
+size_t skimi_vp3d_workspace_bytes(const skimi_vp3d* h, int32_t batch, int32_t frames_in) {
+    if (!h || batch <= 0 || frames_in < skimi_vp3d_receptive_field(h)) return 0;
+    const size_t L0 = (size_t)frames_in - h->fw[0] + 1;
+    const size_t rows = (size_t)batch * L0;
+    const size_t k0 = align_up((size_t)h->fw[0] * h->joints_in * h->in_features, 8);
+    return align_up(rows * k0 * 4, 256) + 4 * align_up(rows * h->channels * 4, 256);
+}
+
+int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch, int32_t frames_in,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    SKIMI_CHECK_ARG(h && x && out && workspace, "skimi_vp3d_forward: null argument");
+    if (!h->finalized) {
+        set_error("skimi_vp3d_forward: weights not finalized");
+        return SKIMI_ERR_STATE;
+    }
+    const int rf = skimi_vp3d_receptive_field(h);
+    SKIMI_CHECK_ARG(batch > 0 && frames_in >= rf, "skimi_vp3d_forward: need frames_in >= receptive field %d", rf);
+    const size_t wsneed = skimi_vp3d_workspace_bytes(h, batch, frames_in);
+    if (workspace_bytes < wsneed) {
+        set_error("skimi_vp3d_forward: workspace %zu < %zu", workspace_bytes, wsneed);
+        return SKIMI_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int C = h->channels, cin0 = h->joints_in * h->in_features;
+    const int L0 = frames_in - h->fw[0] + 1;
+    const size_t rows0 = (size_t)batch * L0;
+    char* ws = (char*)workspace;
+    float* a0 = (float*)ws;
+    ws += align_up(rows0 * h->k0pad * 4, 256);
+    const size_t actb = align_up(rows0 * C * 4, 256);
+    float* bufX = (float*)ws;
+    float* bufY = (float*)(ws + actb);
+    float* bufZ = (float*)(ws + 2 * actb);
+    void* slab = ws + 3 * actb;
+    const int wdt = h->prec == SKIMI_PREC_BF16 ? SKIMI_BF16 : SKIMI_F32;
+
+    int rc;
+    if ((rc = vp3d_im2col_launch(x, a0, batch, frames_in, cin0, h->fw[0], h->k0pad, st))) return rc;
+
+    skimi_gemm_desc d;
+    memset(&d, 0, sizeof d);
+    d.prec = h->prec;
+    d.a_dtype = SKIMI_F32;
+    d.w_dtype = wdt;
+    d.out_dtype = SKIMI_F32;
+    d.splitk_scratch = slab;
+    d.splitk_scratch_bytes = actb;
+    d.act = SKIMI_ACT_RELU;
+
+    // expand: [B*L0, k0pad] x [C, k0pad]^T
+    d.M = (int)rows0; d.N = C; d.K = h->k0pad;
+    d.A = a0; d.lda = h->k0pad;
+    d.W = h->w_expand; d.ldw = h->k0pad;
+    d.bias = h->b_expand;
+    d.out = bufX; d.ldo = C;
+    if ((rc = gemm_dispatch(&d, st, d.splitk_scratch, d.splitk_scratch_bytes, 0))) return rc;
+
+    int L = L0;   // frames held by bufX, per batch element
+    for (size_t i = 1; i < h->fw.size(); ++i) {
+        const int k = h->fw[i], dil = h->dilation[i];
+        const int Lo = L - (k - 1) * dil;
+        SKIMI_CHECK_ARG(Lo > 0, "skimi_vp3d_forward: sequence too short");
+        // conv k, dilated: gather over the [B, 1, L, C] "image"
+        d.a_mode = 1;
+        d.cN = batch; d.cH = 1; d.cW = L; d.cC = C; d.KH = 1; d.KW = k;
+        d.stride = 1; d.pad = 0; d.dil = dil; d.OH = 1; d.OW = Lo;
+        d.M = batch * Lo; d.N = C; d.K = k * C;
+        d.A = bufX; d.lda = C;
+        d.W = h->w_conv[2 * (i - 1)]; d.ldw = (int64_t)k * C;
+        d.bias = h->b_conv[2 * (i - 1)];
+        d.resid = nullptr;
+        d.out = bufY; d.ldo = C;
+        if ((rc = gemm_dispatch(&d, st, d.splitk_scratch, d.splitk_scratch_bytes, 0))) return rc;
+        // conv 1x1 + BN + ReLU, then + res = x[:, pad+shift : L-pad+shift]  (model.py:129-135)
+        d.a_mode = 0;
+        d.K = C;
+        d.A = bufY; d.lda = C;
+        d.W = h->w_conv[2 * (i - 1) + 1]; d.ldw = C;
+        d.bias = h->b_conv[2 * (i - 1) + 1];
+        d.resid = bufX; d.ldr = C;
+        d.resid_rows_per_batch = Lo;
+        d.resid_batch_stride = L;
+        d.resid_row_off = h->pad[i] + h->causal_shift[i];
+        // the epilogue reads residual rows written by other workgroups' inputs, so the
+        // result goes to a third buffer and the buffers rotate
+        d.out = bufZ;
+        if ((rc = gemm_dispatch(&d, st, d.splitk_scratch, d.splitk_scratch_bytes, 0))) return rc;
+        float* t = bufX;
+        bufX = bufZ;
+        bufZ = t;
+        d.resid = nullptr;
+        d.resid_rows_per_batch = 0;
+        d.resid_batch_stride = 0;
+        d.resid_row_off = 0;
+        L = Lo;
+    }
+    // shrink: 1x1 conv with bias, no activation
+    d.a_mode = 0;
+    d.act = SKIMI_ACT_NONE;
+    d.M = batch * L; d.N = h->joints_out * 3; d.K = C;
+    d.A = bufX; d.lda = C;
+    d.W = h->w_shrink; d.ldw = C;
+    d.bias = h->b_shrink;
+    d.out = out; d.ldo = h->joints_out * 3;
+    if ((rc = gemm_dispatch(&d, st, d.splitk_scratch, d.splitk_scratch_bytes, 0))) return rc;
+    return SKIMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+"""Thin torch-tensor wrappers over the generic C-ABI ops (skimi_gemm, skimi_layernorm,
+skimi_qknorm_rope, skimi_attention).  Tensors provide device memory and the stream only; all
+arithmetic happens in libskimi.so.  Used by the parity tests and by the Python host side."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, BF16, F32, PREC_BF16, PREC_BF16X3, GemmDesc, check, lib, ptr
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.SkimiError("libskimi ops need device (HBM) tensors; got a CPU tensor")
+
+
+def gemm(a, w, *, prec=PREC_BF16X3, bias=None, gamma=None, resid=None, act=ACT_NONE, out=None,
+         out_dtype=torch.float32, conv=None, resid_map=None, pixel_shuffle=None, splitk_scratch=None,
+         force_splitk=0, M=None, lda=None):
+    """out = epilogue(gather(a) @ w.T).  a: [rows, lda] (f32|bf16), w: [N, K].
+
+    conv = dict(N,H,W,C,KH,KW,stride,pad,dil,OH,OW) selects the implicit-im2col gather;
+    resid_map = (rows_per_batch, batch_stride, row_off); pixel_shuffle = (s, Cout, N, H, W)."""
+    _require_cuda(a, w, bias, gamma, resid, out)
+    d = GemmDesc()
+    N, K = w.shape
+    d.N, d.K = N, K
+    d.A, d.W = ptr(a), ptr(w)
+    d.a_dtype, d.w_dtype = _dt(a), _dt(w)
+    d.lda = lda if lda is not None else a.stride(-2) if a.dim() >= 2 else a.shape[-1]
+    d.ldw = w.stride(0)
+    d.prec = prec
+    if conv is not None:
+        d.a_mode = 1
+        d.cN, d.cH, d.cW, d.cC = conv["N"], conv["H"], conv["W"], conv["C"]
+        d.KH, d.KW, d.stride, d.pad, d.dil = conv["KH"], conv["KW"], conv["stride"], conv["pad"], conv["dil"]
+        d.OH, d.OW = conv["OH"], conv["OW"]
+        d.M = d.cN * d.OH * d.OW
+    else:
+        d.M = M if M is not None else a.shape[0]
+    if pixel_shuffle is not None:
+        s, cout, n_img, h, w_ = pixel_shuffle
+        d.store_mode, d.ps_s, d.ps_C = 1, s, cout
+        d.cN, d.cH, d.cW = n_img, h, w_
+        if out is None:
+            out = torch.empty((n_img, h * s, w_ * s, cout), dtype=out_dtype, device=a.device)
+        d.ldo = out.stride(-2)
+    else:
+        if out is None:
+            out = torch.empty((d.M, N), dtype=out_dtype, device=a.device)
+        d.ldo = out.stride(-2)
+    d.out, d.out_dtype = ptr(out), _dt(out)
+    d.bias, d.gamma, d.resid = ptr(bias), ptr(gamma), ptr(resid)
+    if resid is not None:
+        d.ldr = resid.stride(-2)
+    if resid_map is not None:
+        d.resid_rows_per_batch, d.resid_batch_stride, d.resid_row_off = resid_map
+    d.act = act
+    if splitk_scratch is not None:
+        d.splitk_scratch = ptr(splitk_scratch)
+        d.splitk_scratch_bytes = splitk_scratch.numel() * splitk_scratch.element_size()
+    d.force_splitk = force_splitk
+    check(lib().skimi_gemm(C.byref(d), _lib.current_stream()), "skimi_gemm")
+    return out
+
+
+def layernorm(x, gamma=None, beta=None, eps=1e-5, *, x2=None, out_dtype=torch.float32):
+    _require_cuda(x, x2, gamma, beta)
+    rows = x.numel() // x.shape[-1]
+    Cc = x.shape[-1] * (2 if x2 is not None else 1)
+    out = torch.empty((*x.shape[:-1], Cc), dtype=out_dtype, device=x.device)
+    check(lib().skimi_layernorm(ptr(x), ptr(x2), x.stride(-2), rows, Cc, ptr(gamma), ptr(beta), eps, ptr(out),
+                                _dt(out), Cc, _lib.current_stream()), "skimi_layernorm")
+    return out
+
+
+def qknorm_rope_(qkv, heads, qn_w=None, qn_b=None, kn_w=None, kn_b=None, eps=1e-5, pos=None, rope_cos=None,
+                 rope_sin=None):
+    """in place on qkv [tokens, 3*heads*64]"""
+    _require_cuda(qkv, pos, rope_cos, rope_sin)
+    tokens = qkv.numel() // (3 * heads * 64)
+    npos = rope_cos.shape[0] if rope_cos is not None else 0
+    check(lib().skimi_qknorm_rope(ptr(qkv), _dt(qkv), tokens, heads, ptr(qn_w), ptr(qn_b), ptr(kn_w), ptr(kn_b),
+                                  eps, ptr(pos), ptr(rope_cos), ptr(rope_sin), npos, _lib.current_stream()),
+          "skimi_qknorm_rope")
+    return qkv
+
+
+def attention(qkv, batch, seq, heads, head_dim):
+    """qkv: [batch*seq, 3*heads*head_dim] -> [batch*seq, heads*head_dim] (same dtype)"""
+    _require_cuda(qkv)
+    out = torch.empty((batch * seq, heads * head_dim), dtype=qkv.dtype, device=qkv.device)
+    check(lib().skimi_attention(ptr(qkv), ptr(out), _dt(qkv), batch, seq, heads, head_dim, _lib.current_stream()),
+          "skimi_attention")
+    return out

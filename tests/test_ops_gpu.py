@@ -1,0 +1,208 @@
+"""GPU parity of the generic C-ABI ops against plain torch fp32 references of the same op."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from skiing_analysis_pytorch_amd import ops
+from skiing_analysis_pytorch_amd._lib import ACT_GELU, ACT_NONE, ACT_RELU, PREC_BF16, PREC_BF16X3
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 104), (1374, 3072, 1024), (8, 6144, 2048), (267, 1024, 3072)])
+@pytest.mark.parametrize("prec", [PREC_BF16X3, PREC_BF16])
+def test_gemm_plain(M, N, K, prec):
+    a, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3)
+    scratch = torch.empty(M * N, dtype=torch.float32, device=DEV)
+    ref = a @ w.T + b
+    wd = w if prec == PREC_BF16X3 else w.to(torch.bfloat16)
+    out = ops.gemm(a, wd, prec=prec, bias=b, splitk_scratch=scratch)
+    torch.cuda.synchronize()
+    tol = 2e-5 if prec == PREC_BF16X3 else 1e-2
+    assert _rel(out, ref) < tol
+    if prec == PREC_BF16:  # bf16 A and bf16 out
+        out2 = ops.gemm(a.to(torch.bfloat16), wd, prec=prec, bias=b, out_dtype=torch.bfloat16)
+        assert _rel(out2.float(), ref) < 2e-2
+
+
+def test_gemm_exact_integers_asymmetric():
+    # exact small-integer data catches any swapped fragment / transposed C map
+    M, N, K = 96, 160, 64
+    a = torch.arange(M * K, device=DEV, dtype=torch.float32).reshape(M, K) % 7 - 3
+    w = (torch.arange(N * K, device=DEV, dtype=torch.float32).reshape(N, K) * 3 % 11) - 5
+    for prec, wd in ((PREC_BF16X3, w), (PREC_BF16, w.to(torch.bfloat16))):
+        out = ops.gemm(a, wd, prec=prec)
+        assert torch.equal(out, a @ w.T)
+
+
+@pytest.mark.parametrize("splitk", [2, 5])
+def test_gemm_splitk(splitk):
+    M, N, K = 100, 192, 1024
+    a, w, b = _rand(M, K, seed=4), _rand(N, K, seed=5, scale=1 / 32), _rand(N, seed=6)
+    scratch = torch.empty(M * N, dtype=torch.float32, device=DEV)
+    out = ops.gemm(a, w, bias=b, act=ACT_RELU, splitk_scratch=scratch, force_splitk=splitk)
+    assert _rel(out, F.relu(a @ w.T + b)) < 2e-5
+
+
+def test_gemm_epilogue_gelu_layerscale_residual():
+    M, N, K = 300, 256, 128
+    a, w, b, g, r = _rand(M, K, seed=7), _rand(N, K, seed=8, scale=0.1), _rand(N, seed=9), _rand(N, seed=10), _rand(M, N, seed=11)
+    out = ops.gemm(a, w, bias=b, act=ACT_GELU)
+    assert _rel(out, F.gelu(a @ w.T + b)) < 2e-5
+    out = ops.gemm(a, w, bias=b, gamma=g, resid=r)
+    assert _rel(out, r + g * (a @ w.T + b)) < 2e-5
+    # in-place residual stream update (out aliases resid), as the transformer blocks do
+    r2 = r.clone()
+    ops.gemm(a, w, bias=b, gamma=g, resid=r2, out=r2)
+    assert _rel(r2, r + g * (a @ w.T + b)) < 2e-5
+    # odd N: scalar epilogue path
+    w51, b51 = _rand(51, K, seed=12, scale=0.1), _rand(51, seed=13)
+    assert _rel(ops.gemm(a, w51, bias=b51), a @ w51.T + b51) < 2e-5
+
+
+@pytest.mark.parametrize("prec", [PREC_BF16X3, PREC_BF16])
+@pytest.mark.parametrize("cfg", [dict(H=37, W=37, C=64, Co=96, k=3, s=1, p=1, d=1), dict(H=37, W=37, C=128, Co=64, k=3, s=2, p=1, d=1),
+                                 dict(H=1, W=90, C=64, Co=64, k=3, s=1, p=0, d=9), dict(H=20, W=24, C=64, Co=32, k=1, s=1, p=0, d=1)])
+def test_gemm_conv_gather(cfg, prec):
+    H, W_, Cc, Co, k, s, p, d = (cfg[x] for x in ("H", "W", "C", "Co", "k", "s", "p", "d"))
+    kh = 1 if H == 1 else k
+    n = 2
+    x = _rand(n, H, W_, Cc, seed=20)                      # channels-last
+    w = _rand(Co, Cc, kh, k, seed=21, scale=1 / math.sqrt(Cc * kh * k))
+    b = _rand(Co, seed=22)
+    pad = (0 if H == 1 else p, p)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=s, padding=pad, dilation=(1 if H == 1 else d, d))
+    OH, OW = ref.shape[2], ref.shape[3]
+    wp = w.permute(0, 2, 3, 1).reshape(Co, kh * k * Cc).contiguous()   # [Co, ky, kx, Cin]
+    if prec == PREC_BF16:
+        wp = wp.to(torch.bfloat16)
+    conv = dict(N=n, H=H, W=W_, C=Cc, KH=kh, KW=k, stride=s, pad=p if H > 1 else 0, dil=d, OH=OH, OW=OW)
+    if H == 1:
+        conv["pad"] = 0
+    out = ops.gemm(x.reshape(-1, Cc), wp, prec=prec, bias=b, conv=conv)
+    ref_cl = ref.permute(0, 2, 3, 1).reshape(-1, Co)
+    assert _rel(out, ref_cl) < (2e-5 if prec == PREC_BF16X3 else 1e-2)
+
+
+def test_gemm_pixel_shuffle_convtranspose():
+    n, H, W_, Cc, Co, s = 2, 9, 7, 64, 32, 4
+    x = _rand(n, H, W_, Cc, seed=30)
+    w = _rand(Cc, Co, s, s, seed=31, scale=0.1)          # ConvTranspose2d weight [Cin, Cout, kH, kW]
+    b = _rand(Co, seed=32)
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2), w, b, stride=s).permute(0, 2, 3, 1)
+    wp = w.permute(2, 3, 1, 0).reshape(s * s * Co, Cc).contiguous()   # [(a,b,co), Cin]
+    out = ops.gemm(x.reshape(-1, Cc), wp, bias=b.repeat(s * s), pixel_shuffle=(s, Co, n, H, W_))
+    assert _rel(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("C", [64, 128, 384, 388, 1024, 2048])
+def test_layernorm(C):
+    x, g, b = _rand(333, C, seed=40), _rand(C, seed=41), _rand(C, seed=42)
+    out = ops.layernorm(x, g, b, 1e-5)
+    ref = F.layer_norm(x, (C,), g, b, 1e-5)
+    assert (out - ref).abs().max().item() < 2e-5
+    assert (ops.layernorm(x, None, None, 1e-6) - F.layer_norm(x, (C,), None, None, 1e-6)).abs().max().item() < 2e-5
+    ob = ops.layernorm(x, g, b, 1e-5, out_dtype=torch.bfloat16)
+    assert (ob.float() - ref).abs().max().item() < 4e-2
+
+
+def test_layernorm_concat():
+    a, b2 = _rand(100, 1024, seed=43), _rand(100, 1024, seed=44)
+    g, b = _rand(2048, seed=45), _rand(2048, seed=46)
+    out = ops.layernorm(a, g, b, 1e-5, x2=b2)
+    ref = F.layer_norm(torch.cat([a, b2], -1), (2048,), g, b, 1e-5)
+    assert (out - ref).abs().max().item() < 2e-5
+
+
+def _rope_tables(npos, base=100.0):
+    # restated from vggt/vggt/layers/rope.py:86-117 (fp32)
+    exponents = torch.arange(0, 32, 2).float() / 32
+    inv_freq = 1.0 / (base ** exponents)
+    ang = torch.einsum("i,j->ij", torch.arange(npos, dtype=inv_freq.dtype), inv_freq)
+    return ang.cos().contiguous(), ang.sin().contiguous()
+
+
+def _rope_ref(t, pos, cos_t, sin_t):
+    # t [B, H, N, 64]; pos [B, N, 2]
+    def rot(x):
+        h = x.shape[-1] // 2
+        return torch.cat((-x[..., h:], x[..., :h]), -1)
+
+    def one(x, p):
+        c = torch.cat((cos_t, cos_t), -1)[p][:, None]
+        s = torch.cat((sin_t, sin_t), -1)[p][:, None]
+        return x * c + rot(x) * s
+
+    v, h = t.chunk(2, -1)
+    return torch.cat((one(v, pos[..., 0]), one(h, pos[..., 1])), -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_qknorm_rope(dtype):
+    tokens, heads = 200, 4
+    qkv = _rand(tokens, 3 * heads * 64, seed=50)
+    qw, qb, kw, kb = (_rand(64, seed=51 + i) for i in range(4))
+    pos = torch.stack([torch.arange(tokens) % 38, (torch.arange(tokens) * 7) % 38], -1).to(torch.int32)
+    cos_t, sin_t = _rope_tables(38)
+    x = qkv.to(dtype).float().cpu().reshape(tokens, 3, heads, 64)
+    q = F.layer_norm(x[:, 0], (64,), qw.cpu(), qb.cpu(), 1e-5)
+    k = F.layer_norm(x[:, 1], (64,), kw.cpu(), kb.cpu(), 1e-5)
+    pl = pos.long()[None]
+    q = _rope_ref(q.permute(1, 0, 2)[None], pl, cos_t, sin_t)[0].permute(1, 0, 2)
+    k = _rope_ref(k.permute(1, 0, 2)[None], pl, cos_t, sin_t)[0].permute(1, 0, 2)
+    ref = torch.stack([q, k, x[:, 2]], 1).reshape(tokens, -1)
+    buf = qkv.to(dtype).clone()
+    ops.qknorm_rope_(buf, heads, qw, qb, kw, kb, 1e-5, pos.to(DEV), cos_t.to(DEV), sin_t.to(DEV))
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert (buf.float().cpu() - ref).abs().max().item() < tol
+    # v untouched, bit for bit
+    assert torch.equal(buf.reshape(tokens, 3, -1)[:, 2], qkv.to(dtype).reshape(tokens, 3, -1)[:, 2])
+
+
+@pytest.mark.parametrize("batch,seq,heads,hd", [(2, 77, 3, 64), (1, 300, 2, 64), (3, 8, 4, 128), (2, 81, 8, 48), (1, 1374, 2, 64)])
+def test_attention_f32(batch, seq, heads, hd):
+    qkv = _rand(batch * seq, 3 * heads * hd, seed=60)
+    out = ops.attention(qkv, batch, seq, heads, hd)
+    x = qkv.reshape(batch, seq, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(x[0].cpu(), x[1].cpu(), x[2].cpu()).transpose(1, 2).reshape(batch * seq, -1)
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("batch,seq,heads", [(2, 77, 3), (1, 300, 2), (2, 1374, 4), (1, 2748, 2), (1, 64, 1), (1, 128, 1)])
+def test_attention_bf16(batch, seq, heads):
+    hd = 64
+    qkv = _rand(batch * seq, 3 * heads * hd, seed=61).to(torch.bfloat16)
+    out = ops.attention(qkv, batch, seq, heads, hd)
+    x = qkv.float().cpu().reshape(batch, seq, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = F.scaled_dot_product_attention(x[0], x[1], x[2]).transpose(1, 2).reshape(batch * seq, -1)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 2e-2, err
+
+
+def test_attention_bf16_online_softmax_rescale():
+    # force the running max to jump at a late tile: one key row aligned with the queries
+    seq, hd = 512, 64
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(seq, hd, generator=g) * 0.5
+    k = torch.randn(seq, hd, generator=g) * 0.5
+    v = torch.randn(seq, hd, generator=g)
+    k[400] = q[5] * 8.0     # spike late in the key sequence for query 5
+    k[70] = q[300] * 8.0
+    qkv = torch.cat([q, k, v], -1).to(torch.bfloat16).to(DEV)
+    out = ops.attention(qkv, 1, seq, 1, hd)
+    x = qkv.float().cpu()
+    ref = F.scaled_dot_product_attention(x[None, None, :, :64], x[None, None, :, 64:128], x[None, None, :, 128:])[0, 0]
+    assert (out.float().cpu() - ref).abs().max().item() < 3e-2

@@ -1,0 +1,71 @@
+"""GPU parity of the HIP TemporalModel lifter through the C-ABI against the oracle and the
+reference's own outputs (tests/golden/vp3d_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vp3d_oracle
+from skiing_analysis_pytorch_amd import vp3d, weights as W
+from skiing_analysis_pytorch_amd._lib import PREC_BF16, PREC_BF16X3
+
+pytestmark = pytest.mark.gpu
+
+TOL_JOINTS = 1e-3   # north_star: output 3D joints within 1e-3 of the reference CPU path
+
+
+def _model(fw, causal, prec):
+    m = vp3d.TemporalModel(17, 2, 17, fw, causal=causal, channels=1024, prec=prec)
+    m.load_state_dict(W.make_vp3d_state_dict(seed=0, filter_widths=fw))
+    return m
+
+
+@pytest.mark.parametrize("name", ["rf27", "rf27_causal", "rf243", "rf81_w5"])
+def test_vp3d_matches_reference_golden(golden_dir, name):
+    g = np.load(golden_dir / f"vp3d_{name}.npz")
+    fw = [int(v) for v in g["filter_widths"]]
+    causal = bool(g["causal"])
+    m = _model(fw, causal, PREC_BF16X3)
+    assert m.receptive_field() == int(g["receptive_field"])
+    for aug in (0, 1):
+        x = torch.from_numpy(g[f"batch2d_aug{aug}"]).cuda()
+        raw = m(x).cpu().numpy()
+        assert raw.shape == g[f"raw_aug{aug}"].shape
+        err = np.abs(raw - g[f"raw_aug{aug}"]).max()
+        assert err < 2e-4, f"{name} aug{aug}: max abs err {err}"
+        pred = vp3d.lift_clip(m, g["keypoints_px"], int(g["w"]), int(g["h"]), augment=bool(aug))
+        mp = vp3d_oracle.mpjpe(pred, g[f"pred_aug{aug}"])
+        assert mp < TOL_JOINTS and np.abs(pred - g[f"pred_aug{aug}"]).max() < TOL_JOINTS
+
+
+def test_vp3d_vs_oracle_other_seed():
+    fw = [3, 3, 3]
+    sd = W.make_vp3d_state_dict(seed=5, filter_widths=fw)
+    m = vp3d.TemporalModel(17, 2, 17, fw, prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    for frames in (1, 27, 100):        # ragged clip lengths incl. a single frame
+        kp = W.make_keypoints_2d(frames=frames, seed=9).numpy()
+        ref = vp3d_oracle.lift_clip(sd, kp, 1920, 1080, fw)
+        out = vp3d.lift_clip(m, kp, 1920, 1080)
+        assert out.shape == (frames, 17, 3)
+        assert np.abs(out - ref).max() < 2e-4
+
+
+def test_vp3d_bf16_mode_tolerance():
+    # plain bf16 operands: documents what the fast mode costs (not the parity mode)
+    fw = [3, 3, 3]
+    sd = W.make_vp3d_state_dict(seed=0, filter_widths=fw)
+    m = vp3d.TemporalModel(17, 2, 17, fw, prec=PREC_BF16)
+    m.load_state_dict(sd)
+    kp = W.make_keypoints_2d(frames=243, seed=1).numpy()
+    ref = vp3d_oracle.lift_clip(sd, kp, 1920, 1080, fw)
+    out = vp3d.lift_clip(m, kp, 1920, 1080)
+    rel = np.linalg.norm(out - ref) / np.linalg.norm(ref)
+    assert rel < 3e-2, rel
+
+
+def test_vp3d_short_input_rejected():
+    from skiing_analysis_pytorch_amd import _lib
+
+    m = _model([3, 3, 3], False, PREC_BF16X3)
+    with pytest.raises(_lib.SkimiError):
+        m(torch.zeros(1, 26, 17, 2, device="cuda"))
