@@ -74,24 +74,25 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a, int
     auto issue = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int key = kt * KV + st_r[i];
-            if (key < a.seq_k) {
-                kreg[i] = *reinterpret_cast<const bf16x8*>(K + (long)key * a.k_row + st_c[i] * 8);
-                vreg[i] = *reinterpret_cast<const bf16x8*>(V + (long)key * a.v_row + st_c[i] * 8);
-            } else {
-                kreg[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                vreg[i] = kreg[i];
-            }
+            // unconditional loads from a clamped row (a predicated load would serialise the burst);
+            // rows past the end are zeroed in registers in write()
+            const int key = min(kt * KV + st_r[i], a.seq_k - 1);
+            kreg[i] = *reinterpret_cast<const bf16x8*>(K + (long)key * a.k_row + st_c[i] * 8);
+            vreg[i] = *reinterpret_cast<const bf16x8*>(V + (long)key * a.v_row + st_c[i] * 8);
         }
     };
     // K rows: chunk ^= (row>>1)&7  (conflict-free ds_read_b128 of 32 rows at one chunk)
     // V rows: chunk ^= ((row>>1)&1)<<2 (conflict-free ds_read_b64_tr_b16 of 4-row blocks)
-    auto write = [&](int buf) {
+    auto write = [&](int buf, int kt) {
         char* kb = smem + buf * 2 * TILE;
         char* vb = kb + TILE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = st_r[i], c = st_c[i];
+            if (kt * KV + r >= a.seq_k) {   // V rows past the end must be finite zeros (0 * NaN)
+                kreg[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                vreg[i] = kreg[i];
+            }
             *reinterpret_cast<bf16x8*>(kb + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kreg[i];
             *reinterpret_cast<bf16x8*>(vb + r * 128 + ((c ^ (((r >> 1) & 1) << 2)) << 4)) = vreg[i];
         }
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a, int
 
     const int nkt = (a.seq_k + KV - 1) / KV;
     issue(0);
-    write(0);
+    write(0, 0);
     __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a, int
             }
         }
 
-        if (kt + 1 < nkt) write(cur ^ 1);
+        if (kt + 1 < nkt) write(cur ^ 1, kt + 1);
         __syncthreads();
     }
 

@@ -169,14 +169,25 @@ template <typename T> struct Stage;
 template <> struct Stage<float> { float4 a, b; };
 template <> struct Stage<unsigned short> { bf16x8 v; };
 
-__device__ __forceinline__ void stage_load(Stage<float>& s, const float* p, bool ok) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    s.a = ok ? *reinterpret_cast<const float4*>(p) : z;
-    s.b = ok ? *reinterpret_cast<const float4*>(p + 4) : z;
+// Loads are UNCONDITIONAL (the caller clamps the address into the buffer): a predicated load
+// compiles to a branch plus a vmcnt(0) at its join, which serialises the whole staging burst.
+// Out-of-range chunks are zeroed in registers (v_cndmask) when they are parked in LDS.
+__device__ __forceinline__ void stage_load(Stage<float>& s, const float* p) {
+    s.a = *reinterpret_cast<const float4*>(p);
+    s.b = *reinterpret_cast<const float4*>(p + 4);
 }
-__device__ __forceinline__ void stage_load(Stage<unsigned short>& s, const unsigned short* p, bool ok) {
-    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    s.v = ok ? *reinterpret_cast<const bf16x8*>(p) : z;
+__device__ __forceinline__ void stage_load(Stage<unsigned short>& s, const unsigned short* p) {
+    s.v = *reinterpret_cast<const bf16x8*>(p);
+}
+__device__ __forceinline__ void stage_mask(Stage<float>& s, bool ok) {
+    s.a.x = ok ? s.a.x : 0.f; s.a.y = ok ? s.a.y : 0.f; s.a.z = ok ? s.a.z : 0.f; s.a.w = ok ? s.a.w : 0.f;
+    s.b.x = ok ? s.b.x : 0.f; s.b.y = ok ? s.b.y : 0.f; s.b.z = ok ? s.b.z : 0.f; s.b.w = ok ? s.b.w : 0.f;
+}
+__device__ __forceinline__ void stage_mask(Stage<unsigned short>& s, bool ok) {
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    i32x4 v = __builtin_bit_cast(i32x4, s.v);
+    v[0] = ok ? v[0] : 0; v[1] = ok ? v[1] : 0; v[2] = ok ? v[2] : 0; v[3] = ok ? v[3] : 0;
+    s.v = __builtin_bit_cast(bf16x8, v);
 }
 __device__ __forceinline__ void split1(float x, short& hi, short& lo) {
     const unsigned short h = f2bf(x);
@@ -295,6 +306,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
+    unsigned okmask = 0;
 
 #define LDS_OFF(r, c) ((r) * RB + ((((c) ^ (((r) / RPB) % CPR))) << 4))
 
@@ -326,13 +338,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                     ok = ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
                     off = ((a_base[i] * p.cH + iy) * p.cW + ix) * p.lda + cin0 + a_c[i] * 8;
                 }
-                stage_load(sa[i], reinterpret_cast<const TA*>(p.A) + (ok ? off : 0), ok);
+                stage_load(sa[i], reinterpret_cast<const TA*>(p.A) + (ok ? off : 0));
+                okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
             }
 #pragma unroll
             for (int i = 0; i < W_IT; ++i) {
                 const int kk = k0 + w_c[i] * 8;
                 const bool ok = w_ok[i] && kk < ke;
-                stage_load(sw[i], reinterpret_cast<const TW*>(p.W) + (ok ? (w_base[i] + kk) : 0), ok);
+                stage_load(sw[i], reinterpret_cast<const TW*>(p.W) + (ok ? (w_base[i] + kk) : 0));
+                okmask = ok ? (okmask | (1u << (16 + i))) : (okmask & ~(1u << (16 + i)));
             }
         }
         if (kt >= 0) {
@@ -374,6 +388,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const int o = LDS_OFF(a_r[i], a_c[i]);
+                stage_mask(sa[i], (okmask >> i) & 1u);
                 if (NSPLIT == 3) {
                     bf16x8 hi, lo;
                     stage_split(sa[i], hi, lo);
@@ -387,6 +402,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < W_IT; ++i) {
                 const int o = LDS_OFF(w_r[i], w_c[i]);
+                stage_mask(sw[i], (okmask >> (16 + i)) & 1u);
                 if (NSPLIT == 3) {
                     bf16x8 hi, lo;
                     stage_split(sw[i], hi, lo);
