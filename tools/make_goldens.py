@@ -76,7 +76,107 @@ def gen_vp3d():
         print("wrote", f"vp3d_{name}.npz", {k: v.shape for k, v in out.items()})
 
 
-GENERATORS = {"vp3d": gen_vp3d}
+TINY_CONFIGS = {
+    # conv patch embed, everything on: exercises aggregator, camera, both DPT heads, track head
+    "tiny_conv": dict(S=3, H=140, W=140, queries=5, cfg=dict(
+        img_size=140, embed_dim=128, depth=4, num_heads=2, patch_embed="conv", cam_trunk_depth=2, cam_heads=2,
+        dpt_features=128, dpt_out_channels=(64, 128, 256, 256), dpt_layers=(0, 1, 2, 3), track_features=64,
+        track_hidden=128, track_corr_levels=3, track_corr_radius=3, track_iters=3, track_depth=2,
+        track_heads=8, track_virtual=16)),
+    # DINOv2 ViT-S/14-reg patch embed (12 blocks, LayerNorm eps 1e-6, LayerScale), no track head
+    "tiny_dino": dict(S=2, H=70, W=70, queries=0, cfg=dict(
+        img_size=70, embed_dim=384, depth=2, num_heads=6, patch_embed="dinov2_vits14_reg", dino_depth=12,
+        dino_heads=6, cam_trunk_depth=1, cam_heads=6, dpt_features=64, dpt_out_channels=(64, 64, 128, 128),
+        dpt_layers=(0, 0, 1, 1), enable_track=False)),
+}
+
+
+def build_reference_vggt(cfg: "W.VGGTConfig"):
+    """The reference VGGT module with non-default sizes: VGGT.__init__ hard-codes VGGT-1B, so the
+    sub-modules are built with the reference's own classes and attached under the same attribute
+    names; forward() is the reference's VGGT.forward unchanged."""
+    import torch.nn as nn
+    from vggt.vggt.heads.camera_head import CameraHead
+    from vggt.vggt.heads.dpt_head import DPTHead
+    from vggt.vggt.heads.track_head import TrackHead
+    from vggt.vggt.models.aggregator import Aggregator
+    from vggt.vggt.models.vggt import VGGT
+
+    m = VGGT.__new__(VGGT)
+    nn.Module.__init__(m)
+    m.aggregator = Aggregator(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim,
+                              depth=cfg.depth, num_heads=cfg.num_heads, patch_embed=cfg.patch_embed)
+    D = 2 * cfg.embed_dim
+    m.camera_head = CameraHead(dim_in=D, trunk_depth=cfg.cam_trunk_depth, num_heads=cfg.cam_heads) if cfg.enable_camera else None
+    dk = dict(dim_in=D, features=cfg.dpt_features, out_channels=list(cfg.dpt_out_channels),
+              intermediate_layer_idx=list(cfg.dpt_layers))
+    m.point_head = DPTHead(output_dim=4, activation="inv_log", conf_activation="expp1", **dk) if cfg.enable_point else None
+    m.depth_head = DPTHead(output_dim=2, activation="exp", conf_activation="expp1", **dk) if cfg.enable_depth else None
+    if cfg.enable_track:
+        th = TrackHead(dim_in=D, patch_size=cfg.patch_size, features=cfg.track_features, iters=cfg.track_iters,
+                       corr_levels=cfg.track_corr_levels, corr_radius=cfg.track_corr_radius,
+                       hidden_size=cfg.track_hidden)
+        # TrackHead builds its DPT with default out_channels/layers and its tracker with depth 6 /
+        # 64 virtual tracks; rebuild those two with the reference classes for the tiny sizes
+        from vggt.vggt.heads.track_modules.base_track_predictor import BaseTrackerPredictor
+        from vggt.vggt.heads.track_modules.blocks import EfficientUpdateFormer
+        th.feature_extractor = DPTHead(dim_in=D, patch_size=cfg.patch_size, features=cfg.track_features,
+                                       out_channels=list(cfg.dpt_out_channels),
+                                       intermediate_layer_idx=list(cfg.dpt_layers), feature_only=True,
+                                       down_ratio=2, pos_embed=False)
+        th.tracker = BaseTrackerPredictor(latent_dim=cfg.track_features, predict_conf=True, stride=2,
+                                          corr_levels=cfg.track_corr_levels, corr_radius=cfg.track_corr_radius,
+                                          hidden_size=cfg.track_hidden, depth=cfg.track_depth)
+        th.tracker.updateformer = EfficientUpdateFormer(
+            space_depth=cfg.track_depth, time_depth=cfg.track_depth, input_dim=3 * cfg.track_features + 4,
+            hidden_size=cfg.track_hidden, num_heads=cfg.track_heads, output_dim=cfg.track_features + 2,
+            mlp_ratio=4.0, add_space_attn=True, num_virtual_tracks=cfg.track_virtual)
+        m.track_head = th
+    else:
+        m.track_head = None
+    return m.eval()
+
+
+def run_reference_vggt(name, cfgd, S, H, W_, nq, seed=0):
+    cfg = W.VGGTConfig(**cfgd)
+    sd = W.make_vggt_state_dict(cfg, seed=seed)
+    m = build_reference_vggt(cfg)
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    images = W.make_images(S, H, W_, seed=seed + 1)
+    q = None
+    if nq:
+        g = torch.Generator().manual_seed(seed + 2)
+        q = torch.rand((nq, 2), generator=g) * torch.tensor([W_ - 20.0, H - 20.0]) + 10.0
+    captured = {}
+    hook = m.aggregator.register_forward_hook(lambda mod, i, o: captured.__setitem__("tokens", o[0]))
+    preds = m(images, query_points=q)
+    hook.remove()
+    out = {"images_seed": np.array(seed + 1), "S": np.array(S), "H": np.array(H), "W": np.array(W_)}
+    if q is not None:
+        out["query_points"] = q.numpy()
+    for k, v in preds.items():
+        if k == "images":
+            continue
+        if k == "pose_enc_list":
+            out[k] = torch.stack(v).numpy()
+        else:
+            out[k] = v.numpy()
+    toks = captured["tokens"]
+    out["tokens_last"] = toks[-1].numpy()
+    out["tokens_first"] = toks[0].numpy()
+    return cfg, out
+
+
+def gen_vggt_tiny():
+    import json
+
+    for name, spec in TINY_CONFIGS.items():
+        cfg, out = run_reference_vggt(name, spec["cfg"], spec["S"], spec["H"], spec["W"], spec["queries"])
+        np.savez_compressed(GOLD / f"vggt_{name}.npz", cfg_json=np.array(json.dumps(spec["cfg"])), seed=np.array(0), **out)
+        print("wrote", f"vggt_{name}.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+GENERATORS = {"vp3d": gen_vp3d, "vggt_tiny": gen_vggt_tiny}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENERATORS)
