@@ -86,13 +86,24 @@ typedef struct skimi_gemm_desc {
      * resid row m' = m + resid_row_off (+ (m / resid_rows_per_batch) * resid_batch_skip) */
     const float* bias;        /* dev [N] or NULL */
     const float* gamma;       /* dev [N] or NULL */
-    const float* resid;       /* dev or NULL */
+    const void* resid;        /* dev or NULL; f32 or bf16 per resid_dtype */
+    int32_t resid_dtype;      /* SKIMI_F32 / SKIMI_BF16, applies to resid and resid2 */
     int64_t ldr;
     int32_t resid_rows_per_batch; /* 0 = no batching of the residual row map */
     int64_t resid_batch_stride;   /* rows between consecutive batches in resid */
     int64_t resid_row_off;
     int32_t act;
-    /* store: store_mode 0 = out[m*ldo + n]; 1 = ConvTranspose2d with kernel == stride
+    /* then: v += resid2[m, n] (plain row m, leading dim ldr2); v = post_act(v) */
+    const void* resid2;       /* dev or NULL */
+    int64_t ldr2;
+    int32_t post_act;
+    /* store_mode 0 output row remap, same form as the residual's:
+     * row = (m / out_rows_per_batch) * out_batch_stride + m % out_rows_per_batch + out_row_off
+     * (out_rows_per_batch 0 = row m + out_row_off) */
+    int32_t out_rows_per_batch;
+    int64_t out_batch_stride;
+    int64_t out_row_off;
+    /* store: store_mode 0 = out[row*ldo + n]; 1 = ConvTranspose2d with kernel == stride
      * (ps_s): m = (img, iy, ix) over [cN, cH, cW], n = (a*ps_s + b)*ps_C + co,
      * out[((img*cH*ps_s + iy*ps_s + a)*cW*ps_s + ix*ps_s + b)*ldo + co] */
     void* out;                /* dev; f32 or bf16 */
@@ -161,6 +172,64 @@ size_t skimi_vp3d_workspace_bytes(const skimi_vp3d*, int32_t batch, int32_t fram
 /* x: dev f32 [batch, frames_in, joints_in, in_features]; out: dev f32
  * [batch, frames_in - rf + 1, joints_out, 3]  (model.py:63-77) */
 int skimi_vp3d_forward(skimi_vp3d*, const float* x, float* out, int32_t batch, int32_t frames_in,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* VGGT forward  (vggt/vggt/models/vggt.py:29-96; call site infer.py:84)      */
+/* ------------------------------------------------------------------------- */
+typedef struct skimi_vggt skimi_vggt;
+
+/* Shape parameters; the defaults of the reference are VGGT() = VGGT-1B
+ * (vggt.py:18-27, aggregator.py:51-70, camera_head.py:26-37, dpt_head.py:40-53,
+ * track_head.py:18-29).  head_dim = embed_dim / num_heads must be 64. */
+typedef struct skimi_vggt_config {
+    int32_t patch_size, embed_dim, depth, num_heads, num_register_tokens;
+    int32_t use_dino;          /* 1: DINOv2 ViT patch embed ("dinov2_vit*14_reg"); 0: conv patch embed */
+    int32_t dino_depth, dino_heads, dino_img_size;   /* dino_img_size: side the pos_embed grid was built for */
+    int32_t cam_trunk_depth, cam_heads, cam_iters;
+    int32_t dpt_features, dpt_out_channels[4], dpt_layers[4];
+    int32_t track_features, track_hidden, track_corr_levels, track_corr_radius, track_iters, track_depth,
+        track_heads, track_virtual;
+    int32_t enable_camera, enable_depth, enable_point, enable_track;
+    /* MFMA mode of the DINOv2 + aggregator blocks and of the track head (bf16 under the
+     * reference's autocast, infer.py:78-84; vggt.py:85 runs the track head inside it) */
+    int32_t prec;
+    /* MFMA mode of the camera/DPT heads, which the reference runs in fp32
+     * (torch.cuda.amp.autocast(enabled=False), vggt.py:65): BF16X3 = faithful, BF16 = fast */
+    int32_t head_prec;
+} skimi_vggt_config;
+
+skimi_vggt* skimi_vggt_create(const skimi_vggt_config* cfg);
+void skimi_vggt_destroy(skimi_vggt*);
+/* one entry of the reference state_dict by key ("aggregator.frame_blocks.3.attn.qkv.weight",
+ * "depth_head.scratch.refinenet1.resConfUnit1.conv1.weight", ...; infer.py:62-67).
+ * data: n fp32 elements on the host (on_device = 0) or already in HBM (on_device = 1). */
+int skimi_vggt_set_weight(skimi_vggt*, const char* key, const float* data, int64_t n, int32_t on_device);
+/* check every key of the configured model is present with the right size, repack
+ * (conv taps, bf16 copies, padded K) and release the staged fp32 copies */
+int skimi_vggt_finalize(skimi_vggt*);
+size_t skimi_vggt_workspace_bytes(skimi_vggt*, int32_t B, int32_t S, int32_t H, int32_t W, int32_t n_query);
+
+/* device output buffers (fp32); a NULL pointer skips the store (a head whose outputs are all
+ * NULL is not run).  Shapes as the reference's prediction dict (vggt.py:40-53). */
+typedef struct skimi_vggt_outputs {
+    float* pose_enc;           /* [B, S, 9] last iteration */
+    float* pose_enc_list;      /* [cam_iters, B, S, 9] */
+    float* depth;              /* [B, S, H, W, 1] */
+    float* depth_conf;         /* [B, S, H, W] */
+    float* world_points;       /* [B, S, H, W, 3] */
+    float* world_points_conf;  /* [B, S, H, W] */
+    float* track;              /* [B, S, N, 2] last iteration */
+    float* vis;                /* [B, S, N] */
+    float* conf;               /* [B, S, N] */
+    float* tokens_last;        /* [B, S, P, 2*embed_dim]: aggregated_tokens_list[-1] (tests) */
+} skimi_vggt_outputs;
+
+/* images: dev f32 [B, S, 3, H, W] in [0, 1]; query_points: dev f32 [B, N, 2] pixels or NULL.
+ * Errors mirror the reference: channels != 3 cannot be expressed (the layout fixes 3);
+ * H or W not a multiple of patch_size -> SKIMI_ERR_ARG (patch_embed.py:69-70). */
+int skimi_vggt_forward(skimi_vggt*, const float* images, const float* query_points, int32_t B, int32_t S,
+                       int32_t H, int32_t W, int32_t n_query, const skimi_vggt_outputs* out,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus

@@ -34,11 +34,14 @@ class GemmDesc(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("dil", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
         ("bias", C.c_void_p), ("gamma", C.c_void_p), ("resid", C.c_void_p),
+        ("resid_dtype", C.c_int32),
         ("ldr", C.c_int64),
         ("resid_rows_per_batch", C.c_int32),
         ("resid_batch_stride", C.c_int64),
         ("resid_row_off", C.c_int64),
         ("act", C.c_int32),
+        ("resid2", C.c_void_p), ("ldr2", C.c_int64), ("post_act", C.c_int32),
+        ("out_rows_per_batch", C.c_int32), ("out_batch_stride", C.c_int64), ("out_row_off", C.c_int64),
         ("out", C.c_void_p), ("out2", C.c_void_p),
         ("out_dtype", C.c_int32),
         ("ldo", C.c_int64), ("ldo2", C.c_int64),
@@ -69,6 +72,13 @@ _SIGNATURES = {
     "skimi_vp3d_receptive_field": (C.c_int32, [_vp]),
     "skimi_vp3d_workspace_bytes": (C.c_size_t, [_vp, C.c_int32, C.c_int32]),
     "skimi_vp3d_forward": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp]),
+    "skimi_vggt_create": (_vp, [_vp]),
+    "skimi_vggt_destroy": (None, [_vp]),
+    "skimi_vggt_set_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, C.c_int32]),
+    "skimi_vggt_finalize": (C.c_int, [_vp]),
+    "skimi_vggt_workspace_bytes": (C.c_size_t, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "skimi_vggt_forward": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp,
+                                     _vp, C.c_size_t, _vp]),
 }
 
 _lib = None

@@ -31,12 +31,19 @@ struct GemmArgs {
     int cN, cH, cW, cC, KH, KW, stride, pad, dil, OH, OW;
     const float* bias;
     const float* gamma;
-    const float* resid;
+    const void* resid;     // f32 or bf16 (resid_dtype)
+    int resid_dtype;
     long ldr;
     int resid_rpb;
     long resid_bs;
     long resid_off;
+    const void* resid2;    // second residual (same dtype), plain row m
+    long ldr2;
+    int out_rpb;           // output row remap (store_mode 0), like the residual's
+    long out_bs;
+    long out_off;
     int act;
+    int post_act;          // activation applied after the residual adds
     void* out;
     void* out2;
     int out_dtype;
@@ -59,18 +66,35 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+__device__ __forceinline__ float load_res(const void* r, int dt, long i) {
+    return dt == SKIMI_F32 ? ((const float*)r)[i] : bf2f(((const unsigned short*)r)[i]);
+}
+__device__ __forceinline__ float4 load_res4(const void* r, int dt, long i) {
+    if (dt == SKIMI_F32) return *reinterpret_cast<const float4*>((const float*)r + i);
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>((const unsigned short*)r + i);
+    return make_float4(bf2f((unsigned short)v[0]), bf2f((unsigned short)v[1]), bf2f((unsigned short)v[2]),
+                       bf2f((unsigned short)v[3]));
+}
+
 // everything that depends only on the output row m
 struct RowMap {
-    long out_off;   // mode 0: m*ldo; mode 1: top-left output pixel index of this input pixel
+    long out_off;   // mode 0: row*ldo; mode 1: top-left output pixel index of this input pixel
     long out2_off;  // same for out2
     long res_off;
+    long res2_off;
 };
 
 __device__ __forceinline__ RowMap row_map(const GemmArgs& p, int m) {
     RowMap r;
     if (p.store_mode == 0) {
-        r.out_off = (long)m * p.ldo;
-        r.out2_off = (long)m * p.ldo2;
+        long mo = m;
+        if (p.out_rpb > 0) {
+            int b = m / p.out_rpb;
+            mo = (long)b * p.out_bs + (m - b * p.out_rpb);
+        }
+        mo += p.out_off;
+        r.out_off = mo * p.ldo;
+        r.out2_off = mo * p.ldo2;
     } else {
         // m = (img, iy, ix) over [cN, cH, cW]
         int hw = p.cH * p.cW;
@@ -88,6 +112,7 @@ __device__ __forceinline__ RowMap row_map(const GemmArgs& p, int m) {
         mr = (long)b * p.resid_bs + (m - b * p.resid_rpb);
     }
     r.res_off = (mr + p.resid_off) * p.ldr;
+    r.res2_off = (long)m * p.ldr2;
     return r;
 }
 
@@ -96,7 +121,9 @@ __device__ __forceinline__ void store_one(const GemmArgs& p, const RowMap& rm, i
     if (p.bias) v += p.bias[n];
     v = apply_act(v, p.act);
     if (p.gamma) v *= p.gamma[n];
-    if (p.resid) v += p.resid[rm.res_off + n];
+    if (p.resid) v += load_res(p.resid, p.resid_dtype, rm.res_off + n);
+    if (p.resid2) v += load_res(p.resid2, p.resid_dtype, rm.res2_off + n);
+    v = apply_act(v, p.post_act);
     long o, o2;
     if (p.store_mode == 0) {
         o = rm.out_off + n;
@@ -134,8 +161,16 @@ __device__ __forceinline__ void store_four(const GemmArgs& p, const RowMap& rm, 
         v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
     }
     if (p.resid) {
-        const float4 r = *reinterpret_cast<const float4*>(p.resid + rm.res_off + n);
+        const float4 r = load_res4(p.resid, p.resid_dtype, rm.res_off + n);
         v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    if (p.resid2) {
+        const float4 r = load_res4(p.resid2, p.resid_dtype, rm.res2_off + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    if (p.post_act != SKIMI_ACT_NONE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], p.post_act);
     }
     long o, o2;
     if (p.store_mode == 0) {
@@ -516,6 +551,7 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
                         (long)d->cN * d->cH * d->cW == d->M, "skimi_gemm: bad pixel-shuffle store geometry");
     }
     if (d->resid) SKIMI_CHECK_ARG(d->ldr >= d->N, "skimi_gemm: ldr < N");
+    if (d->resid2) SKIMI_CHECK_ARG(d->ldr2 >= d->N, "skimi_gemm: ldr2 < N");
 
     GemmArgs a;
     a.M = d->M; a.N = d->N; a.K = d->K;
@@ -523,8 +559,11 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     a.a_mode = d->a_mode;
     a.cN = d->cN; a.cH = d->cH; a.cW = d->cW; a.cC = d->cC; a.KH = d->KH; a.KW = d->KW;
     a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.OH = d->OH; a.OW = d->OW;
-    a.bias = d->bias; a.gamma = d->gamma; a.resid = d->resid; a.ldr = d->ldr;
+    a.bias = d->bias; a.gamma = d->gamma; a.resid = d->resid; a.ldr = d->ldr; a.resid_dtype = d->resid_dtype;
     a.resid_rpb = d->resid_rows_per_batch; a.resid_bs = d->resid_batch_stride; a.resid_off = d->resid_row_off;
+    a.resid2 = d->resid2; a.ldr2 = d->ldr2;
+    a.out_rpb = d->out_rows_per_batch; a.out_bs = d->out_batch_stride; a.out_off = d->out_row_off;
+    a.post_act = d->post_act;
     a.act = d->act;
     a.out = d->out; a.out2 = d->out2; a.out_dtype = d->out_dtype; a.ldo = d->ldo; a.ldo2 = d->ldo2;
     a.store_mode = d->store_mode; a.ps_s = d->ps_s; a.ps_C = d->ps_C;
@@ -535,7 +574,8 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
         const bool out2_ok = !d->out2 || (d->out_dtype == SKIMI_F32 ? (((uintptr_t)d->out2 & 7) == 0) : al16(d->out2));
         a.vec4 = (d->N % 4 == 0) && (d->ldo % 4 == 0) && (!d->out2 || d->ldo2 % 4 == 0) && out_ok && out2_ok &&
                  (!d->bias || al16(d->bias)) && (!d->gamma || al16(d->gamma)) &&
-                 (!d->resid || (al16(d->resid) && d->ldr % 4 == 0)) && (d->store_mode == 0 || d->ps_C % 4 == 0);
+                 (!d->resid || ((((uintptr_t)d->resid) & 7) == 0 && (d->resid_dtype != SKIMI_F32 || al16(d->resid)) && d->ldr % 4 == 0)) &&
+                 (!d->resid2 || ((((uintptr_t)d->resid2) & 7) == 0 && (d->resid_dtype != SKIMI_F32 || al16(d->resid2)) && d->ldr2 % 4 == 0)) && (d->store_mode == 0 || d->ps_C % 4 == 0);
     }
 
     // tile + split-K choice: fill >= ~256 CUs

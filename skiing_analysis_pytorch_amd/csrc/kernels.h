@@ -9,7 +9,8 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
 
 int layernorm_launch(const float* x, const float* x2, int64_t ldx, int64_t rows, int C,
                      const float* gamma, const float* beta, float eps, void* out, int out_dtype,
-                     int64_t ldo, hipStream_t st);
+                     int64_t ldo, hipStream_t st, int64_t grp_rows = 0, int64_t grp_stride = 0,
+                     int64_t grp_off = 0);
 
 int qknorm_rope_launch(void* qkv, int dtype, int64_t tokens, int heads, const float* qn_w,
                        const float* qn_b, const float* kn_w, const float* kn_b, float eps,

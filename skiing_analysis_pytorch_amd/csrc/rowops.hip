@@ -18,10 +18,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ x2, long ldx, long rows,
                                                         int C, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, void* out,
-                                                        int out_dtype, long ldo) {
+                                                        int out_dtype, long ldo, long grp_rows,
+                                                        long grp_stride, long grp_off) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long orow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (orow >= rows) return;
+    // optional input row gather: output row r reads input row (r / grp_rows)*grp_stride + grp_off + r % grp_rows
+    const long row = grp_rows > 0 ? (orow / grp_rows) * grp_stride + grp_off + orow % grp_rows : orow;
     const int half = C >> 1;
     float v[MAXV];
     float s = 0.f;
@@ -52,19 +55,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             float y = (v[i] - mean) * rstd;
             if (gamma) y *= gamma[c];
             if (beta) y += beta[c];
-            if (out_dtype == SKIMI_F32) ((float*)out)[row * ldo + c] = y;
-            else ((unsigned short*)out)[row * ldo + c] = f2bf(y);
+            if (out_dtype == SKIMI_F32) ((float*)out)[orow * ldo + c] = y;
+            else ((unsigned short*)out)[orow * ldo + c] = f2bf(y);
         }
     }
 }
 
 int layernorm_launch(const float* x, const float* x2, int64_t ldx, int64_t rows, int C, const float* gamma,
-                     const float* beta, float eps, void* out, int out_dtype, int64_t ldo, hipStream_t st) {
+                     const float* beta, float eps, void* out, int out_dtype, int64_t ldo, hipStream_t st,
+                     int64_t grp_rows, int64_t grp_stride, int64_t grp_off) {
     SKIMI_CHECK_ARG(x && out && rows > 0 && C > 0, "skimi_layernorm: bad arguments");
     SKIMI_CHECK_ARG(C <= 64 * 32, "skimi_layernorm: C=%d exceeds 2048", C);
     SKIMI_CHECK_ARG(x2 == nullptr || (C % 2 == 0), "skimi_layernorm: concat needs even C");
     dim3 grid((unsigned)cdiv(rows, 4)), block(256);
-#define LN_GO(V) hipLaunchKernelGGL(layernorm_kernel<V>, grid, block, 0, st, x, x2, (long)ldx, (long)rows, C, gamma, beta, eps, out, out_dtype, (long)ldo)
+#define LN_GO(V) hipLaunchKernelGGL(layernorm_kernel<V>, grid, block, 0, st, x, x2, (long)ldx, (long)rows, C, gamma, beta, eps, out, out_dtype, (long)ldo, (long)grp_rows, (long)grp_stride, (long)grp_off)
     const int nv = (int)cdiv(C, 64);
     if (nv <= 2) LN_GO(2);
     else if (nv <= 8) LN_GO(8);

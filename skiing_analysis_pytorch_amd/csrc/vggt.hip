@@ -1,0 +1,952 @@
+// VGGT forward on MI355X: the graph of fused MFMA contractions, flash attention and row-wise
+// kernels that replaces `preds = self.vggt(imgs)` (vggt/vggt/infer.py:84).
+//
+// Data layout in HBM (all channels-last, row-major):
+//   residual stream x      fp32 [F*P, C]          F = B*S frames, P = 1 + R + ph*pw tokens
+//   GEMM operands          bf16 (PREC_BF16) or fp32 (PREC_BF16X3) [rows, C | 3C | 4C]
+//   kept intermediates     fp32 [F*P, C] x {frame, global} for the 4 DPT layers + the last layer;
+//                          the reference's torch.cat([frame, global], -1) (aggregator.py:250-253) is
+//                          never materialised: consumers read the two halves through two pointers
+//   DPT feature maps       [F, h, w, C] (NHWC), 3x3 / strided / transposed convs as implicit-gather GEMMs
+// Weights are repacked once in skimi_vggt_finalize (conv taps -> [Cout, ky, kx, Cin], ConvTranspose
+// -> pixel-shuffle GEMM, bf16 copies, K padded to 8).  The forward allocates nothing: every
+// activation lives in the caller's workspace through a bump arena whose peak is computed by a
+// dry run of the same code (skimi_vggt_workspace_bytes).
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "vggt_kernels.h"
+
+using namespace skimi;
+
+namespace {
+
+struct Lin {              // out = A . W^T (+ b)
+    void* w = nullptr;    // [N, ldw] bf16 or f32
+    int wdt = SKIMI_F32;
+    float* b = nullptr;
+    int N = 0, K = 0;     // K as seen by the GEMM (padded)
+    int prec = SKIMI_PREC_BF16X3;
+};
+struct LNw { float* g = nullptr; float* b = nullptr; };
+struct BlockW {
+    LNw n1, n2;
+    Lin qkv, proj, fc1, fc2;
+    float *ls1 = nullptr, *ls2 = nullptr;
+    float *qn_w = nullptr, *qn_b = nullptr, *kn_w = nullptr, *kn_b = nullptr;
+};
+struct ConvW { Lin lin; int k = 1, stride = 1, pad = 0, cin = 0; };
+struct FusionW { Lin out_conv; ConvW r1c1, r1c2, r2c1, r2c2; bool has_r1 = false; };
+struct DptW {
+    LNw norm;
+    Lin proj[4];
+    Lin rs0, rs1;       // ConvTranspose k=s=4 / 2 as pixel-shuffle GEMMs (bias tiled s*s times)
+    ConvW rs3;
+    ConvW rn[4];
+    FusionW ref[4];     // ref[0] = refinenet1 ... ref[3] = refinenet4
+    ConvW oc1, oc2a;
+    float *oc2b_w = nullptr, *oc2b_b = nullptr;
+    int n_out = 0, features = 0, oc[4] = {0, 0, 0, 0};
+    bool feature_only = false, pos_embed = true;
+    int down_ratio = 1;
+};
+struct CamW {
+    std::vector<BlockW> trunk;
+    LNw token_norm, trunk_norm;
+    float* empty16 = nullptr;   // empty_pose_tokens padded to 16
+    Lin embed_pose, poseLN, fc1, fc2;
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0, peak = 0, cap = 0;
+    bool dry = false, overflow = false;
+    void* alloc(size_t bytes) {
+        off = align_up(off, 256);
+        void* p = dry ? (void*)(uintptr_t)(0x1000 + off) : (void*)(base + off);
+        off += bytes;
+        if (off > peak) peak = off;
+        if (!dry && off > cap) overflow = true;
+        return p;
+    }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+};
+
+struct UvTab { int w, h, C; float* tx; float* ty; };
+
+}  // namespace
+
+struct skimi_vggt {
+    skimi_vggt_config cfg;
+    std::map<std::string, std::pair<float*, int64_t>> raw;   // staged fp32 weights (device)
+    std::vector<void*> owned;                                // packed device buffers
+    bool finalized = false;
+    // packed model
+    Lin patch_proj;                 // [C, Kp] patchify GEMM (K = 3*p*p padded to 8)
+    int patch_kp = 0;
+    float* dino_pos = nullptr;      // pos_embed [1 + np0, C]
+    float* dino_special = nullptr;  // [2][1+R][C] (cls + pos[0], registers), both selector rows equal
+    float* agg_special = nullptr;   // [2][1+R][C] camera/register tokens for frame 0 / others
+    std::vector<BlockW> dino, frame, global;
+    LNw dino_norm;
+    CamW cam;
+    DptW depth, point, trackf;
+    // per-resolution tables (prepare())
+    int prepH = 0, prepW = 0, prepF = 0;
+    int* pos = nullptr;             // int32 [F*P, 2]
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    int rope_npos = 0;
+    std::vector<UvTab> uv;
+    std::vector<void*> prep_owned;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// finalize helpers
+// ------------------------------------------------------------------------------------------
+struct Packer {
+    skimi_vggt* h;
+    int rc = SKIMI_OK;
+    hipStream_t st = nullptr;
+
+    float* raw(const std::string& key, int64_t n) {
+        if (rc) return nullptr;
+        auto it = h->raw.find(key);
+        if (it == h->raw.end()) {
+            set_error("skimi_vggt_finalize: missing weight '%s'", key.c_str());
+            rc = SKIMI_ERR_STATE;
+            return nullptr;
+        }
+        if (it->second.second != n) {
+            set_error("skimi_vggt_finalize: weight '%s' has %ld elements, expected %ld", key.c_str(),
+                      (long)it->second.second, (long)n);
+            rc = SKIMI_ERR_STATE;
+            return nullptr;
+        }
+        return it->second.first;
+    }
+    void* dmalloc(size_t bytes) {
+        if (rc) return nullptr;
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            set_error("skimi_vggt_finalize: hipMalloc(%zu) failed", bytes);
+            rc = SKIMI_ERR_HIP;
+            return nullptr;
+        }
+        h->owned.push_back(p);
+        return p;
+    }
+    // a plain fp32 parameter used as is (LN affine, bias, LayerScale, tokens): private copy
+    float* keep(const std::string& key, int64_t n) {
+        float* src = raw(key, n);
+        if (!src) return nullptr;
+        float* dst = (float*)dmalloc(n * 4);
+        if (dst && hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = SKIMI_ERR_HIP;
+        return dst;
+    }
+    LNw ln(const std::string& p, int C) { return LNw{keep(p + ".weight", C), keep(p + ".bias", C)}; }
+
+    // matrix [N, K] fp32 on device (owned by caller) -> Lin in the requested precision, K padded to 8
+    Lin pack_matrix(float* src, int N, int K, int prec) {
+        Lin L;
+        L.N = N;
+        L.K = (int)align_up((size_t)K, 8);
+        L.prec = prec;
+        if (rc) return L;
+        float* m = src;
+        if (L.K != K) {
+            m = (float*)dmalloc((size_t)N * L.K * 4);
+            if (m && (rc = pad_cols_launch(src, m, N, K, L.K, st))) return L;
+        }
+        if (prec == SKIMI_PREC_BF16) {
+            void* b = dmalloc((size_t)N * L.K * 2);
+            if (b) rc = f32_to_bf16_launch(m, b, (long)N * L.K, st);
+            L.w = b;
+            L.wdt = SKIMI_BF16;
+        } else {
+            if (m == src) {   // private copy: the staged buffer is released after finalize
+                m = (float*)dmalloc((size_t)N * L.K * 4);
+                if (m && hipMemcpyAsync(m, src, (size_t)N * L.K * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    rc = SKIMI_ERR_HIP;
+            }
+            L.w = m;
+            L.wdt = SKIMI_F32;
+        }
+        return L;
+    }
+    Lin linear(const std::string& p, int N, int K, int prec, bool bias = true) {
+        Lin L = pack_matrix(raw(p + ".weight", (int64_t)N * K), N, K, prec);
+        if (bias) L.b = keep(p + ".bias", N);
+        return L;
+    }
+    // nn.MultiheadAttention style names
+    Lin linear_named(const std::string& wkey, const std::string& bkey, int N, int K, int prec) {
+        Lin L = pack_matrix(raw(wkey, (int64_t)N * K), N, K, prec);
+        L.b = keep(bkey, N);
+        return L;
+    }
+    ConvW conv(const std::string& p, int Co, int Ci, int k, int stride, int pad, int prec, bool bias) {
+        ConvW c;
+        c.k = k; c.stride = stride; c.pad = pad; c.cin = Ci;
+        float* src = raw(p + ".weight", (int64_t)Co * Ci * k * k);
+        if (rc) return c;
+        float* perm = src;
+        float* tmp = nullptr;
+        if (k > 1) {
+            if (hipMalloc((void**)&tmp, (size_t)Co * Ci * k * k * 4) != hipSuccess) { rc = SKIMI_ERR_HIP; return c; }
+            if ((rc = permute_conv_launch(src, tmp, Co, Ci, k, k, st))) return c;
+            perm = tmp;
+        }
+        c.lin = pack_matrix(perm, Co, Ci * k * k, prec);
+        if (tmp) { (void)hipStreamSynchronize(st); (void)hipFree(tmp); }
+        if (bias) c.lin.b = keep(p + ".bias", Co);
+        return c;
+    }
+    // ConvTranspose2d(C, C, k = s, stride = s): [(a,b,co), Ci] weight, bias tiled s*s times
+    Lin convT(const std::string& p, int C, int s, int prec) {
+        Lin L;
+        float* src = raw(p + ".weight", (int64_t)C * C * s * s);
+        float* bsrc = raw(p + ".bias", C);
+        if (rc) return L;
+        float* tmp = nullptr;
+        if (hipMalloc((void**)&tmp, (size_t)C * C * s * s * 4) != hipSuccess) { rc = SKIMI_ERR_HIP; return L; }
+        if ((rc = permute_convT_launch(src, tmp, C, C, s, st))) return L;
+        L = pack_matrix(tmp, s * s * C, C, prec);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(tmp);
+        L.b = (float*)dmalloc((size_t)s * s * C * 4);
+        if (L.b) rc = rc ? rc : tile_vec_launch(bsrc, L.b, C, s * s, st);
+        return L;
+    }
+    BlockW block(const std::string& p, int C, int hidden, bool qk_norm, int hd, int prec) {
+        BlockW b;
+        b.n1 = ln(p + ".norm1", C);
+        b.n2 = ln(p + ".norm2", C);
+        b.qkv = linear(p + ".attn.qkv", 3 * C, C, prec);
+        b.proj = linear(p + ".attn.proj", C, C, prec);
+        b.fc1 = linear(p + ".mlp.fc1", hidden, C, prec);
+        b.fc2 = linear(p + ".mlp.fc2", C, hidden, prec);
+        b.ls1 = keep(p + ".ls1.gamma", C);
+        b.ls2 = keep(p + ".ls2.gamma", C);
+        if (qk_norm) {
+            b.qn_w = keep(p + ".attn.q_norm.weight", hd);
+            b.qn_b = keep(p + ".attn.q_norm.bias", hd);
+            b.kn_w = keep(p + ".attn.k_norm.weight", hd);
+            b.kn_b = keep(p + ".attn.k_norm.bias", hd);
+        }
+        return b;
+    }
+    DptW dpt(const std::string& p, int D, int features, const int* oc, int n_out, bool feature_only, int prec) {
+        DptW d;
+        d.features = features;
+        d.n_out = n_out;
+        d.feature_only = feature_only;
+        for (int i = 0; i < 4; ++i) d.oc[i] = oc[i];
+        d.norm = ln(p + ".norm", D);
+        for (int i = 0; i < 4; ++i) d.proj[i] = linear(p + ".projects." + std::to_string(i), oc[i], D, prec);
+        d.rs0 = convT(p + ".resize_layers.0", oc[0], 4, prec);
+        d.rs1 = convT(p + ".resize_layers.1", oc[1], 2, prec);
+        d.rs3 = conv(p + ".resize_layers.3", oc[3], oc[3], 3, 2, 1, prec, true);
+        for (int i = 0; i < 4; ++i)
+            d.rn[i] = conv(p + ".scratch.layer" + std::to_string(i + 1) + "_rn", features, oc[i], 3, 1, 1, prec, false);
+        for (int r = 0; r < 4; ++r) {
+            const std::string rp = p + ".scratch.refinenet" + std::to_string(r + 1);
+            FusionW& f = d.ref[r];
+            f.out_conv = linear(rp + ".out_conv", features, features, prec);
+            f.has_r1 = r != 3;
+            if (f.has_r1) {
+                f.r1c1 = conv(rp + ".resConfUnit1.conv1", features, features, 3, 1, 1, prec, true);
+                f.r1c2 = conv(rp + ".resConfUnit1.conv2", features, features, 3, 1, 1, prec, true);
+            }
+            f.r2c1 = conv(rp + ".resConfUnit2.conv1", features, features, 3, 1, 1, prec, true);
+            f.r2c2 = conv(rp + ".resConfUnit2.conv2", features, features, 3, 1, 1, prec, true);
+        }
+        if (feature_only) {
+            d.oc1 = conv(p + ".scratch.output_conv1", features, features, 3, 1, 1, prec, true);
+        } else {
+            d.oc1 = conv(p + ".scratch.output_conv1", features / 2, features, 3, 1, 1, prec, true);
+            d.oc2a = conv(p + ".scratch.output_conv2.0", 32, features / 2, 3, 1, 1, prec, true);
+            d.oc2b_w = keep(p + ".scratch.output_conv2.2.weight", (int64_t)n_out * 32);
+            d.oc2b_b = keep(p + ".scratch.output_conv2.2.bias", n_out);
+        }
+        return d;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// forward context
+// ------------------------------------------------------------------------------------------
+struct Ctx {
+    skimi_vggt* h;
+    hipStream_t st;
+    Arena ar;
+    int rc = SKIMI_OK;
+    void* slab = nullptr;      // split-K scratch
+    size_t slab_bytes = 0;
+
+    bool dry() const { return ar.dry; }
+    static int act_dt(int prec) { return prec == SKIMI_PREC_BF16 ? SKIMI_BF16 : SKIMI_F32; }
+    static size_t esz(int dt) { return dt == SKIMI_F32 ? 4 : 2; }
+
+    void gemm(skimi_gemm_desc& d) {
+        if (rc || dry()) return;
+        rc = gemm_dispatch(&d, st, slab, slab_bytes, 0);
+    }
+    skimi_gemm_desc desc(const Lin& L, const void* A, int a_dt, long lda, int M, void* out, int out_dt, long ldo) {
+        skimi_gemm_desc d;
+        memset(&d, 0, sizeof d);
+        d.M = M; d.N = L.N; d.K = L.K;
+        d.A = A; d.a_dtype = a_dt; d.lda = lda;
+        d.W = L.w; d.w_dtype = L.wdt; d.ldw = L.K;
+        d.prec = L.prec;
+        d.bias = L.b;
+        d.out = out; d.out_dtype = out_dt; d.ldo = ldo;
+        return d;
+    }
+    void conv_geom(skimi_gemm_desc& d, const ConvW& c, int N, int H, int W, int OH, int OW) {
+        if (c.k == 1 && c.stride == 1) return;   // plain rows
+        d.a_mode = 1;
+        d.cN = N; d.cH = H; d.cW = W; d.cC = c.cin; d.KH = c.k; d.KW = c.k;
+        d.stride = c.stride; d.pad = c.pad; d.dil = 1; d.OH = OH; d.OW = OW;
+    }
+    void ln(const float* x, const float* x2, long ldx, long rows, int C, const LNw& w, float eps, void* out, int odt,
+            long grp_rows = 0, long grp_stride = 0, long grp_off = 0) {
+        if (rc || dry()) return;
+        rc = layernorm_launch(x, x2, ldx, rows, C, w.g, w.b, eps, out, odt, C, st, grp_rows, grp_stride, grp_off);
+    }
+    void copy(void* dst, const void* src, size_t bytes) {
+        if (rc || dry()) return;
+        if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("hipMemcpyAsync failed");
+            rc = SKIMI_ERR_HIP;
+        }
+    }
+};
+
+// one pre-LN transformer block on the fp32 residual stream x [batch*seq, C]
+// (vggt/vggt/layers/block.py:77-98 + attention.py:50-72), scratch buffers supplied by the caller
+struct BlockBufs { void* xn; void* qkv; void* ao; void* hid; };
+
+void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int heads, float eps, bool rope,
+               const BlockBufs& b) {
+    const int M = batch * seq;
+    const int prec = w.qkv.prec;
+    const int adt = Ctx::act_dt(prec);
+    const int hidden = w.fc1.N;
+    c.ln(x, nullptr, C, M, C, w.n1, eps, b.xn, adt);
+    {
+        auto d = c.desc(w.qkv, b.xn, adt, C, M, b.qkv, adt, 3 * C);
+        c.gemm(d);
+    }
+    if (!c.rc && !c.dry() && (w.qn_w || rope)) {
+        c.rc = qknorm_rope_launch(b.qkv, adt, M, heads, w.qn_w, w.qn_b, w.kn_w, w.kn_b, 1e-5f, rope ? c.h->pos : nullptr,
+                                  c.h->rope_cos, c.h->rope_sin, c.h->rope_npos, c.st);
+    }
+    if (!c.rc && !c.dry()) c.rc = attention_launch(b.qkv, b.ao, adt, batch, seq, heads, C / heads, c.st);
+    {
+        auto d = c.desc(w.proj, b.ao, adt, C, M, x, SKIMI_F32, C);
+        d.gamma = w.ls1; d.resid = x; d.ldr = C;
+        c.gemm(d);
+    }
+    c.ln(x, nullptr, C, M, C, w.n2, eps, b.xn, adt);
+    {
+        auto d = c.desc(w.fc1, b.xn, adt, C, M, b.hid, adt, hidden);
+        d.act = SKIMI_ACT_GELU;
+        c.gemm(d);
+    }
+    {
+        auto d = c.desc(w.fc2, b.hid, adt, hidden, M, x, SKIMI_F32, C);
+        d.gamma = w.ls2; d.resid = x; d.ldr = C;
+        c.gemm(d);
+    }
+}
+
+const UvTab* find_uv(const skimi_vggt* h, int w, int hh, int C) {
+    for (const auto& t : h->uv)
+        if (t.w == w && t.h == hh && t.C == C) return &t;
+    return nullptr;
+}
+
+// DPT head (vggt/vggt/heads/dpt_head.py:172-291) on the kept intermediates.
+// Returns the NHWC feature map pointer for feature_only heads; otherwise writes pts / conf.
+void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, int P, int nsp, int ph, int pw, int C,
+              int H, int W, float* pts, float* conf, int act_mode) {
+    const int prec = w.proj[0].prec;
+    const int adt = Ctx::act_dt(prec);
+    const size_t es = Ctx::esz(adt);
+    const int D = 2 * C, np = ph * pw, feat = w.features;
+    const size_t mk = c.ar.mark();
+    // resized pyramid sizes
+    int hh[4] = {ph * 4, ph * 2, ph, (ph - 1) / 2 + 1};
+    int ww[4] = {pw * 4, pw * 2, pw, (pw - 1) / 2 + 1};
+    void* rn[4];
+    for (int i = 0; i < 4; ++i) rn[i] = c.ar.alloc((size_t)F * hh[i] * ww[i] * feat * es);
+    {
+        const size_t mk2 = c.ar.mark();
+        void* lnb = c.ar.alloc((size_t)F * np * D * es);
+        for (int i = 0; i < 4; ++i) {
+            const size_t mk3 = c.ar.mark();
+            c.ln(sf[i], sg[i], C, (long)F * np, D, w.norm, 1e-5f, lnb, adt, np, P, nsp);
+            void* t0 = c.ar.alloc((size_t)F * np * w.oc[i] * es);
+            {
+                auto d = c.desc(w.proj[i], lnb, adt, D, F * np, t0, adt, w.oc[i]);
+                c.gemm(d);
+            }
+            if (w.pos_embed && !c.rc && !c.dry()) {
+                const UvTab* t = find_uv(c.h, pw, ph, w.oc[i]);
+                if (!t) { set_error("uv table missing"); c.rc = SKIMI_ERR_STATE; }
+                else c.rc = add_uv_pos_launch(t0, adt, t->tx, t->ty, F, ph, pw, w.oc[i], c.st);
+            }
+            void* t1 = t0;
+            if (i == 0 || i == 1) {
+                const int s = i == 0 ? 4 : 2;
+                const Lin& L = i == 0 ? w.rs0 : w.rs1;
+                t1 = c.ar.alloc((size_t)F * hh[i] * ww[i] * w.oc[i] * es);
+                auto d = c.desc(L, t0, adt, w.oc[i], F * np, t1, adt, w.oc[i]);
+                d.store_mode = 1; d.ps_s = s; d.ps_C = w.oc[i];
+                d.cN = F; d.cH = ph; d.cW = pw;
+                c.gemm(d);
+            } else if (i == 3) {
+                t1 = c.ar.alloc((size_t)F * hh[i] * ww[i] * w.oc[i] * es);
+                auto d = c.desc(w.rs3.lin, t0, adt, w.oc[i], F * hh[i] * ww[i], t1, adt, w.oc[i]);
+                c.conv_geom(d, w.rs3, F, ph, pw, hh[i], ww[i]);
+                c.gemm(d);
+            }
+            // layerN_rn: 3x3, no bias; its only consumer is a ResidualConvUnit whose in-place ReLU
+            // rewrites it (dpt_head.py:376), so the ReLU is applied here once
+            {
+                auto d = c.desc(w.rn[i].lin, t1, adt, w.oc[i], F * hh[i] * ww[i], rn[i], adt, feat);
+                c.conv_geom(d, w.rn[i], F, hh[i], ww[i], hh[i], ww[i]);
+                d.act = SKIMI_ACT_RELU;
+                c.gemm(d);
+            }
+            c.ar.release(mk3);
+        }
+        c.ar.release(mk2);
+    }
+    // RefineNet fusion 4 -> 1 (dpt_head.py:261-291, 427-456)
+    void* prev = nullptr;   // previous refinenet output at this level's resolution
+    for (int r = 3; r >= 0; --r) {
+        const FusionW& f = w.ref[r];
+        const int h0 = hh[r], w0 = ww[r];
+        const int M = F * h0 * w0;
+        const size_t bytes = (size_t)M * feat * es;
+        void* cur;   // relu(input of resConfUnit2)
+        void* tmp = c.ar.alloc(bytes);
+        if (f.has_r1) {
+            // res = RCU1(layer_rn): conv2(relu(conv1(relu(x)))) + relu(x); output = prev + res;
+            // RCU2's in-place ReLU then rewrites output -> store relu(prev + res) directly
+            cur = c.ar.alloc(bytes);
+            auto d1 = c.desc(f.r1c1.lin, rn[r], adt, feat, M, tmp, adt, feat);
+            c.conv_geom(d1, f.r1c1, F, h0, w0, h0, w0);
+            d1.act = SKIMI_ACT_RELU;
+            c.gemm(d1);
+            auto d2 = c.desc(f.r1c2.lin, tmp, adt, feat, M, cur, adt, feat);
+            c.conv_geom(d2, f.r1c2, F, h0, w0, h0, w0);
+            d2.resid = rn[r]; d2.ldr = feat; d2.resid_dtype = adt;
+            d2.resid2 = prev; d2.ldr2 = feat;
+            d2.post_act = SKIMI_ACT_RELU;
+            c.gemm(d2);
+        } else {
+            cur = rn[r];
+        }
+        // RCU2(cur): conv2(relu(conv1(cur))) + cur
+        void* u = c.ar.alloc(bytes);
+        {
+            auto d1 = c.desc(f.r2c1.lin, cur, adt, feat, M, tmp, adt, feat);
+            c.conv_geom(d1, f.r2c1, F, h0, w0, h0, w0);
+            d1.act = SKIMI_ACT_RELU;
+            c.gemm(d1);
+            auto d2 = c.desc(f.r2c2.lin, tmp, adt, feat, M, u, adt, feat);
+            c.conv_geom(d2, f.r2c2, F, h0, w0, h0, w0);
+            d2.resid = cur; d2.ldr = feat; d2.resid_dtype = adt;
+            c.gemm(d2);
+        }
+        // bilinear (align_corners) to the next level's size (x2 for refinenet1), then out_conv 1x1
+        const int h1 = r > 0 ? hh[r - 1] : 2 * h0, w1 = r > 0 ? ww[r - 1] : 2 * w0;
+        void* up = c.ar.alloc((size_t)F * h1 * w1 * feat * es);
+        if (!c.rc && !c.dry()) c.rc = bilinear_ac_launch(u, up, adt, F, h0, w0, h1, w1, feat, c.st);
+        void* o = c.ar.alloc((size_t)F * h1 * w1 * feat * es);
+        {
+            auto d = c.desc(f.out_conv, up, adt, feat, F * h1 * w1, o, adt, feat);
+            c.gemm(d);
+        }
+        prev = o;
+        hh[r] = h1; ww[r] = w1;   // resolution of `prev`
+    }
+    const int h1 = hh[0], w1 = ww[0];
+    const int f2 = w.feature_only ? feat : feat / 2;
+    void* c1 = c.ar.alloc((size_t)F * h1 * w1 * f2 * es);
+    {
+        auto d = c.desc(w.oc1.lin, prev, adt, feat, F * h1 * w1, c1, adt, f2);
+        c.conv_geom(d, w.oc1, F, h1, w1, h1, w1);
+        c.gemm(d);
+    }
+    const int Ho = ph * c.h->cfg.patch_size / w.down_ratio, Wo = pw * c.h->cfg.patch_size / w.down_ratio;
+    void* c1u = c.ar.alloc((size_t)F * Ho * Wo * f2 * es);
+    if (!c.rc && !c.dry()) c.rc = bilinear_ac_launch(c1, c1u, adt, F, h1, w1, Ho, Wo, f2, c.st);
+    if (w.pos_embed && !c.rc && !c.dry()) {
+        const UvTab* t = find_uv(c.h, Wo, Ho, f2);
+        if (!t) { set_error("uv table missing"); c.rc = SKIMI_ERR_STATE; }
+        else c.rc = add_uv_pos_launch(c1u, adt, t->tx, t->ty, F, Ho, Wo, f2, c.st);
+    }
+    if (w.feature_only) return c1u;   // caller releases the arena
+    void* c2 = c.ar.alloc((size_t)F * Ho * Wo * 32 * es);
+    {
+        auto d = c.desc(w.oc2a.lin, c1u, adt, f2, F * Ho * Wo, c2, adt, 32);
+        c.conv_geom(d, w.oc2a, F, Ho, Wo, Ho, Wo);
+        d.act = SKIMI_ACT_RELU;
+        c.gemm(d);
+    }
+    if (!c.rc && !c.dry())
+        c.rc = dpt_out_launch(c2, adt, w.oc2b_w, w.oc2b_b, w.n_out, pts, conf, (long)F * Ho * Wo, act_mode, c.st);
+    c.ar.release(mk);
+    (void)H; (void)W;
+    return nullptr;
+}
+
+// camera head (vggt/vggt/heads/camera_head.py:73-141), fp32 activations
+void run_camera(Ctx& c, const CamW& w, const float* sf, const float* sg, int B, int S, int P, int C, float* out_list,
+                float* out_last) {
+    const skimi_vggt_config& cfg = c.h->cfg;
+    const int R = B * S, D = 2 * C;
+    const size_t mk = c.ar.mark();
+    float* pose_tokens = (float*)c.ar.alloc((size_t)R * D * 4);
+    float* xn = (float*)c.ar.alloc((size_t)R * D * 4);
+    float* xc = (float*)c.ar.alloc((size_t)R * D * 4);
+    float* e = (float*)c.ar.alloc((size_t)R * D * 4);
+    float* mod = (float*)c.ar.alloc((size_t)R * 3 * D * 4);
+    float* pred16 = (float*)c.ar.alloc((size_t)R * 16 * 4);
+    float* t2 = (float*)c.ar.alloc((size_t)R * (D / 2) * 4);
+    float* delta = (float*)c.ar.alloc((size_t)R * 9 * 4);
+    BlockBufs bb;
+    bb.xn = c.ar.alloc((size_t)R * D * 4);
+    bb.qkv = c.ar.alloc((size_t)R * 3 * D * 4);
+    bb.ao = c.ar.alloc((size_t)R * D * 4);
+    bb.hid = c.ar.alloc((size_t)R * 4 * D * 4);
+    // camera token = token 0 of every frame of the last [frame | global] intermediate
+    c.ln(sf, sg, (long)P * C, R, D, w.token_norm, 1e-5f, pose_tokens, SKIMI_F32);
+    LNw none;
+    for (int it = 0; it < cfg.cam_iters; ++it) {
+        if (it == 0 && !c.rc && !c.dry()) c.rc = tile_vec_launch(w.empty16, pred16, 16, R, c.st);
+        {
+            auto d = c.desc(w.embed_pose, pred16, SKIMI_F32, 16, R, e, SKIMI_F32, D);
+            d.act = SKIMI_ACT_SILU;   // poseLN_modulation = Sequential(SiLU, Linear)
+            c.gemm(d);
+        }
+        {
+            auto d = c.desc(w.poseLN, e, SKIMI_F32, D, R, mod, SKIMI_F32, 3 * D);
+            c.gemm(d);
+        }
+        c.ln(pose_tokens, nullptr, D, R, D, none, 1e-6f, xn, SKIMI_F32);
+        if (!c.rc && !c.dry()) c.rc = adaln_launch(xn, pose_tokens, mod, xc, R, D, c.st);
+        for (const BlockW& b : w.trunk) run_block(c, b, xc, B, S, D, cfg.cam_heads, 1e-5f, false, bb);
+        c.ln(xc, nullptr, D, R, D, w.trunk_norm, 1e-5f, xn, SKIMI_F32);
+        {
+            auto d = c.desc(w.fc1, xn, SKIMI_F32, D, R, t2, SKIMI_F32, D / 2);
+            d.act = SKIMI_ACT_GELU;
+            c.gemm(d);
+        }
+        {
+            auto d = c.desc(w.fc2, t2, SKIMI_F32, D / 2, R, delta, SKIMI_F32, 9);
+            c.gemm(d);
+        }
+        float* dst = out_list ? out_list + (size_t)it * R * 9 : (it == cfg.cam_iters - 1 ? out_last : xn /*scratch*/);
+        if (!c.rc && !c.dry()) c.rc = pose_update_launch(delta, pred16, dst, R, it == 0, c.st);
+        if (it == cfg.cam_iters - 1 && out_list && out_last) c.copy(out_last, dst, (size_t)R * 9 * 4);
+    }
+    c.ar.release(mk);
+}
+
+int prepare(skimi_vggt* h, int F, int S, int H, int W) {
+    if (h->prepH == H && h->prepW == W && h->prepF == F) return SKIMI_OK;
+    (void)S;
+    for (void* p : h->prep_owned) (void)hipFree(p);
+    h->prep_owned.clear();
+    h->uv.clear();
+    const skimi_vggt_config& cfg = h->cfg;
+    const int p = cfg.patch_size, ph = H / p, pw = W / p, nsp = 1 + cfg.num_register_tokens, P = nsp + ph * pw;
+    auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+        SKIMI_HIP(hipMalloc(dst, bytes));
+        h->prep_owned.push_back(*dst);
+        SKIMI_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return SKIMI_OK;
+    };
+    int rc;
+    // positions: (y, x) + 1 for patches, 0 for the special tokens (rope.py:39-59, aggregator.py:219-228)
+    std::vector<int> pos((size_t)F * P * 2, 0);
+    for (int f = 0; f < F; ++f)
+        for (int y = 0; y < ph; ++y)
+            for (int x = 0; x < pw; ++x) {
+                const size_t i = ((size_t)f * P + nsp + (size_t)y * pw + x) * 2;
+                pos[i] = y + 1;
+                pos[i + 1] = x + 1;
+            }
+    if ((rc = up(pos.data(), pos.size() * 4, (void**)&h->pos))) return rc;
+    // RoPE tables (rope.py:86-117), fp32 arithmetic as torch: 1/100^(i/16), pos*inv_freq, cos/sin
+    const int npos = std::max(ph, pw) + 1;
+    std::vector<float> cs((size_t)npos * 16), sn((size_t)npos * 16);
+    for (int i = 0; i < 16; ++i) {
+        const float expo = (float)(2 * i) / 32.0f;
+        const float inv = 1.0f / powf(100.0f, expo);
+        for (int q = 0; q < npos; ++q) {
+            const float a = (float)q * inv;
+            cs[(size_t)q * 16 + i] = cosf(a);
+            sn[(size_t)q * 16 + i] = sinf(a);
+        }
+    }
+    if ((rc = up(cs.data(), cs.size() * 4, (void**)&h->rope_cos))) return rc;
+    if ((rc = up(sn.data(), sn.size() * 4, (void**)&h->rope_sin))) return rc;
+    h->rope_npos = npos;
+    // UV sin/cos tables (heads/utils.py:11-109 via dpt_head.py:249-259), float64 then float, x 0.1
+    auto add_uv = [&](int w, int hh, int C) -> int {
+        if (find_uv(h, w, hh, C)) return SKIMI_OK;
+        const double aspect = (double)W / (double)H;
+        const double diag = sqrt(aspect * aspect + 1.0);
+        const double sx = aspect / diag, sy = 1.0 / diag;
+        const int half = C / 2, quarter = C / 4;
+        std::vector<float> tx((size_t)w * half), ty((size_t)hh * half);
+        auto fill = [&](std::vector<float>& tab, int n, double span) {
+            // torch.linspace(-span*(n-1)/n, span*(n-1)/n, n) in float32
+            const float lo = (float)(-span * (n - 1) / n), hi = (float)(span * (n - 1) / n);
+            const float step = n > 1 ? (hi - lo) / (float)(n - 1) : 0.f;
+            for (int i = 0; i < n; ++i) {
+                const float pv = i < n / 2 ? lo + step * (float)i : hi - step * (float)(n - 1 - i);
+                for (int j = 0; j < quarter; ++j) {
+                    const double omega = 1.0 / pow(100.0, (double)j / (double)quarter);
+                    const double a = (double)pv * omega;
+                    tab[(size_t)i * half + j] = (float)sin(a) * 0.1f;
+                    tab[(size_t)i * half + quarter + j] = (float)cos(a) * 0.1f;
+                }
+            }
+        };
+        fill(tx, w, sx);
+        fill(ty, hh, sy);
+        UvTab t{w, hh, C, nullptr, nullptr};
+        int r2;
+        if ((r2 = up(tx.data(), tx.size() * 4, (void**)&t.tx))) return r2;
+        if ((r2 = up(ty.data(), ty.size() * 4, (void**)&t.ty))) return r2;
+        h->uv.push_back(t);
+        return SKIMI_OK;
+    };
+    if (cfg.enable_depth || cfg.enable_point) {
+        for (int i = 0; i < 4; ++i)
+            if ((rc = add_uv(pw, ph, cfg.dpt_out_channels[i]))) return rc;
+        if ((rc = add_uv(pw * p, ph * p, cfg.dpt_features / 2))) return rc;
+    }
+    h->prepH = H; h->prepW = W; h->prepF = F;
+    return SKIMI_OK;
+}
+
+int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query, int B, int S, int H, int W, int nq,
+                 const skimi_vggt_outputs* out) {
+    const skimi_vggt_config& cfg = h->cfg;
+    const int p = cfg.patch_size, C = cfg.embed_dim, ph = H / p, pw = W / p, np = ph * pw;
+    const int nsp = 1 + cfg.num_register_tokens, P = nsp + np, F = B * S, M = F * P;
+    const int prec = cfg.prec, adt = Ctx::act_dt(prec);
+    const size_t es = Ctx::esz(adt);
+    (void)query; (void)nq;
+
+    // split-K slab: large enough for the skinny camera-head / small-config GEMMs
+    c.slab_bytes = std::max<size_t>((size_t)F * 6 * C * 4 * 4, 1u << 20);
+    c.slab = c.ar.alloc(c.slab_bytes);
+
+    float* x = (float*)c.ar.alloc((size_t)M * C * 4);
+    // kept intermediates
+    std::vector<int> keep;
+    auto want = [&](int l) { for (int k : keep) if (k == l) return; keep.push_back(l); };
+    const bool run_depth = cfg.enable_depth && out && (out->depth || out->depth_conf);
+    const bool run_point = cfg.enable_point && out && (out->world_points || out->world_points_conf);
+    const bool run_cam = cfg.enable_camera && out && (out->pose_enc || out->pose_enc_list);
+    const bool run_track = cfg.enable_track && out && out->track && query && nq > 0;
+    if (run_depth || run_point || run_track) for (int i = 0; i < 4; ++i) want(cfg.dpt_layers[i]);
+    if (run_cam || (out && out->tokens_last)) want(cfg.depth - 1);
+    std::map<int, std::pair<float*, float*>> saved;
+    for (int l : keep) {
+        float* a = (float*)c.ar.alloc((size_t)M * C * 4);
+        float* b = (float*)c.ar.alloc((size_t)M * C * 4);
+        saved[l] = {a, b};
+    }
+    {
+        const size_t mk = c.ar.mark();
+        BlockBufs bb;
+        bb.xn = c.ar.alloc((size_t)M * C * es);
+        bb.qkv = c.ar.alloc((size_t)M * 3 * C * es);
+        bb.ao = c.ar.alloc((size_t)M * C * es);
+        bb.hid = c.ar.alloc((size_t)M * 4 * C * es);
+        // ---- patch embed (aggregator.py:195-208) ----
+        void* pa = c.ar.alloc((size_t)F * np * h->patch_kp * es);
+        if (!c.rc && !c.dry()) c.rc = patch_gather_launch(images, pa, adt, F, H, W, p, h->patch_kp, c.st);
+        {
+            auto d = c.desc(h->patch_proj, pa, adt, h->patch_kp, F * np, x, SKIMI_F32, C);
+            d.out_rows_per_batch = np; d.out_batch_stride = P; d.out_row_off = nsp;
+            if (cfg.use_dino) {
+                // + pos_embed[1 + p] (vision_transformer.py:221), broadcast over frames
+                d.resid = h->dino_pos; d.ldr = C;
+                d.resid_rows_per_batch = np; d.resid_batch_stride = 0; d.resid_row_off = 1;
+            }
+            c.gemm(d);
+        }
+        if (cfg.use_dino) {
+            if (!c.rc && !c.dry()) c.rc = special_tokens_launch(x, h->dino_special, F, S, P, nsp, C, c.st);
+            for (const BlockW& b : h->dino) run_block(c, b, x, F, P, C, cfg.dino_heads, 1e-6f, false, bb);
+            // x_norm_patchtokens (vision_transformer.py:264-268): LayerNorm in place (row-local)
+            c.ln(x, nullptr, C, M, C, h->dino_norm, 1e-6f, x, SKIMI_F32);
+        }
+        // camera / register tokens, frame 0 vs others (aggregator.py:210-217, 308-331)
+        if (!c.rc && !c.dry()) c.rc = special_tokens_launch(x, h->agg_special, F, S, P, nsp, C, c.st);
+        // ---- alternating attention (aggregator.py:237-253) ----
+        for (int i = 0; i < cfg.depth && !c.rc; ++i) {
+            run_block(c, h->frame[i], x, F, P, C, cfg.num_heads, 1e-5f, true, bb);
+            auto it = saved.find(i);
+            if (it != saved.end()) c.copy(it->second.first, x, (size_t)M * C * 4);
+            run_block(c, h->global[i], x, B, S * P, C, cfg.num_heads, 1e-5f, true, bb);
+            if (it != saved.end()) c.copy(it->second.second, x, (size_t)M * C * 4);
+        }
+        c.ar.release(mk);
+    }
+    if (out && out->tokens_last && !c.rc && !c.dry()) {
+        // [B,S,P,2C] = cat(frame, global) of the last layer: two strided 2-D copies
+        auto& sv = saved[cfg.depth - 1];
+        if (hipMemcpy2DAsync(out->tokens_last, (size_t)2 * C * 4, sv.first, (size_t)C * 4, (size_t)C * 4, M,
+                             hipMemcpyDeviceToDevice, c.st) != hipSuccess ||
+            hipMemcpy2DAsync(out->tokens_last + C, (size_t)2 * C * 4, sv.second, (size_t)C * 4, (size_t)C * 4, M,
+                             hipMemcpyDeviceToDevice, c.st) != hipSuccess) {
+            set_error("hipMemcpy2DAsync failed");
+            c.rc = SKIMI_ERR_HIP;
+        }
+    }
+    if (run_cam) {
+        auto& sv = saved[cfg.depth - 1];
+        run_camera(c, h->cam, sv.first, sv.second, B, S, P, C, out->pose_enc_list, out->pose_enc);
+    }
+    float* sf[4];
+    float* sg[4];
+    if (run_depth || run_point || run_track)
+        for (int i = 0; i < 4; ++i) {
+            sf[i] = saved[cfg.dpt_layers[i]].first;
+            sg[i] = saved[cfg.dpt_layers[i]].second;
+        }
+    if (run_depth) {
+        float* pts = out->depth ? out->depth : (float*)c.ar.alloc((size_t)F * H * W * 4);
+        float* cf = out->depth_conf ? out->depth_conf : (float*)c.ar.alloc((size_t)F * H * W * 4);
+        run_dpt(c, h->depth, sf, sg, F, P, nsp, ph, pw, C, H, W, pts, cf, 0);
+    }
+    if (run_point) {
+        float* pts = out->world_points ? out->world_points : (float*)c.ar.alloc((size_t)F * H * W * 3 * 4);
+        float* cf = out->world_points_conf ? out->world_points_conf : (float*)c.ar.alloc((size_t)F * H * W * 4);
+        run_dpt(c, h->point, sf, sg, F, P, nsp, ph, pw, C, H, W, pts, cf, 1);
+    }
+    if (run_track) {
+        set_error("skimi_vggt_forward: track head not built yet");
+        c.rc = SKIMI_ERR_STATE;
+    }
+    return c.rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+skimi_vggt* skimi_vggt_create(const skimi_vggt_config* cfg) {
+    if (!cfg) { set_error("skimi_vggt_create: null config"); return nullptr; }
+    if (cfg->embed_dim <= 0 || cfg->num_heads <= 0 || cfg->embed_dim / cfg->num_heads != 64 ||
+        cfg->embed_dim % cfg->num_heads != 0) {
+        set_error("skimi_vggt_create: embed_dim / num_heads must be 64");
+        return nullptr;
+    }
+    if (cfg->use_dino && cfg->embed_dim / cfg->dino_heads != 64) {
+        set_error("skimi_vggt_create: DINOv2 head_dim must be 64");
+        return nullptr;
+    }
+    if (cfg->patch_size <= 0 || cfg->depth <= 0 || cfg->num_register_tokens < 0) {
+        set_error("skimi_vggt_create: bad sizes");
+        return nullptr;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (cfg->dpt_layers[i] < 0 || cfg->dpt_layers[i] >= cfg->depth) {
+            set_error("skimi_vggt_create: dpt_layers[%d] = %d outside [0, depth)", i, cfg->dpt_layers[i]);
+            return nullptr;
+        }
+    skimi_vggt* h = new skimi_vggt();
+    h->cfg = *cfg;
+    return h;
+}
+
+void skimi_vggt_destroy(skimi_vggt* h) {
+    if (!h) return;
+    for (auto& kv : h->raw) (void)hipFree(kv.second.first);
+    for (void* p : h->owned) (void)hipFree(p);
+    for (void* p : h->prep_owned) (void)hipFree(p);
+    delete h;
+}
+
+int skimi_vggt_set_weight(skimi_vggt* h, const char* key, const float* data, int64_t n, int32_t on_device) {
+    SKIMI_CHECK_ARG(h && key && data && n > 0, "skimi_vggt_set_weight: bad arguments");
+    float* d = nullptr;
+    SKIMI_HIP(hipMalloc((void**)&d, (size_t)n * 4));
+    hipError_t e = hipMemcpy(d, data, (size_t)n * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        set_error("skimi_vggt_set_weight: copy failed: %s", hipGetErrorString(e));
+        return SKIMI_ERR_HIP;
+    }
+    auto it = h->raw.find(key);
+    if (it != h->raw.end()) (void)hipFree(it->second.first);
+    h->raw[key] = {d, n};
+    h->finalized = false;
+    return SKIMI_OK;
+}
+
+int skimi_vggt_finalize(skimi_vggt* h) {
+    SKIMI_CHECK_ARG(h, "skimi_vggt_finalize: null handle");
+    const skimi_vggt_config& cfg = h->cfg;
+    for (void* p : h->owned) (void)hipFree(p);
+    h->owned.clear();
+    Packer pk{h};
+    const int C = cfg.embed_dim, p = cfg.patch_size, R = cfg.num_register_tokens, nsp = 1 + R;
+    const int hidden = 4 * C, D = 2 * C;
+    const std::string A = "aggregator";
+    const int kraw = 3 * p * p;
+    // ---- patch embed ----
+    const std::string pe = cfg.use_dino ? A + ".patch_embed.patch_embed.proj" : A + ".patch_embed.proj";
+    h->patch_proj = pk.linear(pe, C, kraw, cfg.prec);
+    h->patch_kp = h->patch_proj.K;
+    if (cfg.use_dino) {
+        const std::string d = A + ".patch_embed";
+        const int g = cfg.dino_img_size / p, np0 = g * g;
+        h->dino_pos = pk.keep(d + ".pos_embed", (int64_t)(np0 + 1) * C);
+        float* cls = pk.raw(d + ".cls_token", C);
+        float* reg = R ? pk.raw(d + ".register_tokens", (int64_t)R * C) : nullptr;
+        (void)pk.raw(d + ".mask_token", C);   // present in the state_dict, unused in inference
+        h->dino_special = (float*)pk.dmalloc((size_t)2 * nsp * C * 4);
+        if (!pk.rc) {
+            // row 0 = cls + pos_embed[0] (vision_transformer.py:220-221), rows 1..R = registers
+            std::vector<float> hc(C), hp(C), hr((size_t)R * C), tab((size_t)2 * nsp * C);
+            SKIMI_HIP(hipMemcpy(hc.data(), cls, C * 4, hipMemcpyDeviceToHost));
+            SKIMI_HIP(hipMemcpy(hp.data(), h->dino_pos, C * 4, hipMemcpyDeviceToHost));
+            if (R) SKIMI_HIP(hipMemcpy(hr.data(), reg, (size_t)R * C * 4, hipMemcpyDeviceToHost));
+            for (int s = 0; s < 2; ++s) {
+                for (int c = 0; c < C; ++c) tab[((size_t)s * nsp) * C + c] = hc[c] + hp[c];
+                for (int r = 0; r < R; ++r)
+                    for (int c = 0; c < C; ++c) tab[((size_t)s * nsp + 1 + r) * C + c] = hr[(size_t)r * C + c];
+            }
+            SKIMI_HIP(hipMemcpy(h->dino_special, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        }
+        h->dino.clear();
+        for (int i = 0; i < cfg.dino_depth; ++i)
+            h->dino.push_back(pk.block(d + ".blocks." + std::to_string(i), C, hidden, false, 64, cfg.prec));
+        h->dino_norm = pk.ln(d + ".norm", C);
+    }
+    // camera_token [1,2,1,C], register_token [1,2,R,C] -> table [2][1+R][C]
+    {
+        float* cam = pk.raw(A + ".camera_token", (int64_t)2 * C);
+        float* reg = R ? pk.raw(A + ".register_token", (int64_t)2 * R * C) : nullptr;
+        h->agg_special = (float*)pk.dmalloc((size_t)2 * nsp * C * 4);
+        if (!pk.rc) {
+            for (int s = 0; s < 2; ++s) {
+                SKIMI_HIP(hipMemcpy(h->agg_special + (size_t)s * nsp * C, cam + (size_t)s * C, C * 4, hipMemcpyDeviceToDevice));
+                if (R) SKIMI_HIP(hipMemcpy(h->agg_special + ((size_t)s * nsp + 1) * C, reg + (size_t)s * R * C,
+                                           (size_t)R * C * 4, hipMemcpyDeviceToDevice));
+            }
+        }
+    }
+    h->frame.clear();
+    h->global.clear();
+    for (int i = 0; i < cfg.depth; ++i) h->frame.push_back(pk.block(A + ".frame_blocks." + std::to_string(i), C, hidden, true, 64, cfg.prec));
+    for (int i = 0; i < cfg.depth; ++i) h->global.push_back(pk.block(A + ".global_blocks." + std::to_string(i), C, hidden, true, 64, cfg.prec));
+    // ---- camera head: fp32 (BF16X3) always ----
+    if (cfg.enable_camera) {
+        const std::string Hc = "camera_head";
+        const int X3 = SKIMI_PREC_BF16X3;
+        h->cam.trunk.clear();
+        for (int i = 0; i < cfg.cam_trunk_depth; ++i)
+            h->cam.trunk.push_back(pk.block(Hc + ".trunk." + std::to_string(i), D, 4 * D, false, 0, X3));
+        h->cam.token_norm = pk.ln(Hc + ".token_norm", D);
+        h->cam.trunk_norm = pk.ln(Hc + ".trunk_norm", D);
+        float* ept = pk.raw(Hc + ".empty_pose_tokens", 9);
+        h->cam.empty16 = (float*)pk.dmalloc(16 * 4);
+        if (!pk.rc) pk.rc = pad_cols_launch(ept, h->cam.empty16, 1, 9, 16, pk.st);
+        h->cam.embed_pose = pk.linear(Hc + ".embed_pose", D, 9, X3);   // K padded to 16
+        h->cam.poseLN = pk.linear(Hc + ".poseLN_modulation.1", 3 * D, D, X3);
+        h->cam.fc1 = pk.linear(Hc + ".pose_branch.fc1", D / 2, D, X3);
+        h->cam.fc2 = pk.linear(Hc + ".pose_branch.fc2", 9, D / 2, X3);
+    }
+    if (cfg.enable_point) h->point = pk.dpt("point_head", D, cfg.dpt_features, cfg.dpt_out_channels, 4, false, cfg.head_prec);
+    if (cfg.enable_depth) h->depth = pk.dpt("depth_head", D, cfg.dpt_features, cfg.dpt_out_channels, 2, false, cfg.head_prec);
+    if (pk.rc) return pk.rc;
+    SKIMI_HIP(hipStreamSynchronize(pk.st));
+    // release the staged fp32 copies (track-head keys stay staged until that head is packed)
+    for (auto it = h->raw.begin(); it != h->raw.end();) {
+        if (it->first.rfind("track_head.", 0) == 0) { ++it; continue; }
+        (void)hipFree(it->second.first);
+        it = h->raw.erase(it);
+    }
+    h->finalized = true;
+    return SKIMI_OK;
+}
+
+static int check_shape(const skimi_vggt* h, int B, int S, int H, int W) {
+    SKIMI_CHECK_ARG(B > 0 && S > 0, "skimi_vggt: B and S must be positive");
+    const int p = h->cfg.patch_size;
+    // patch_embed.py:69-70
+    SKIMI_CHECK_ARG(H > 0 && H % p == 0, "Input image height %d is not a multiple of patch height %d", H, p);
+    SKIMI_CHECK_ARG(W > 0 && W % p == 0, "Input image width %d is not a multiple of patch width: %d", W, p);
+    if (h->cfg.use_dino)
+        SKIMI_CHECK_ARG(H == W && H == h->cfg.dino_img_size,
+                        "DINOv2 pos_embed interpolation for %dx%d (model built for %d) is not built yet", H, W,
+                        h->cfg.dino_img_size);
+    return SKIMI_OK;
+}
+
+size_t skimi_vggt_workspace_bytes(skimi_vggt* h, int32_t B, int32_t S, int32_t H, int32_t W, int32_t n_query) {
+    if (!h || check_shape(h, B, S, H, W)) return 0;
+    Ctx c{h, nullptr};
+    c.ar.dry = true;
+    skimi_vggt_outputs all;
+    memset(&all, 0, sizeof all);
+    // assume every enabled head runs and writes straight to caller buffers
+    float* one = (float*)(uintptr_t)16;
+    all.pose_enc = all.pose_enc_list = all.depth = all.depth_conf = all.world_points = all.world_points_conf = one;
+    all.tokens_last = one;
+    (void)n_query;
+    forward_impl(h, c, nullptr, nullptr, B, S, H, W, 0, &all);
+    return align_up(c.ar.peak, 256) + 256;
+}
+
+int skimi_vggt_forward(skimi_vggt* h, const float* images, const float* query_points, int32_t B, int32_t S, int32_t H,
+                       int32_t W, int32_t n_query, const skimi_vggt_outputs* out, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+    SKIMI_CHECK_ARG(h && images && out && workspace, "skimi_vggt_forward: null argument");
+    if (!h->finalized) {
+        set_error("skimi_vggt_forward: weights not finalized");
+        return SKIMI_ERR_STATE;
+    }
+    int rc;
+    if ((rc = check_shape(h, B, S, H, W))) return rc;
+    if ((rc = prepare(h, B * S, S, H, W))) return rc;
+    Ctx c{h, (hipStream_t)stream};
+    c.ar.base = (char*)workspace;
+    c.ar.cap = workspace_bytes;
+    // refuse before launching anything if the arena cannot hold the plan
+    {
+        Ctx dry{h, nullptr};
+        dry.ar.dry = true;
+        forward_impl(h, dry, images, query_points, B, S, H, W, n_query, out);
+        if (dry.ar.peak > workspace_bytes) {
+            set_error("skimi_vggt_forward: workspace %zu < %zu", workspace_bytes, dry.ar.peak);
+            return SKIMI_ERR_WORKSPACE;
+        }
+    }
+    return forward_impl(h, c, images, query_points, B, S, H, W, n_query, out);
+}
+
+}  // extern "C"

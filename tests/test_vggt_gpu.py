@@ -1,0 +1,91 @@
+"""GPU parity of the HIP VGGT forward (through the C-ABI) against the reference's own outputs
+(tests/golden/vggt_tiny_*.npz) and the oracle."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vggt_oracle
+from skiing_analysis_pytorch_amd import vggt, weights as W
+from skiing_analysis_pytorch_amd._lib import PREC_BF16, PREC_BF16X3
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, name):
+    g = np.load(golden_dir / f"vggt_{name}.npz")
+    cfg = W.VGGTConfig(**json.loads(str(g["cfg_json"])))
+    sd = W.make_vggt_state_dict(cfg, seed=int(g["seed"]))
+    images = W.make_images(int(g["S"]), int(g["H"]), int(g["W"]), seed=int(g["images_seed"]))
+    return g, cfg, sd, images
+
+
+def _maxerr(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+@pytest.mark.parametrize("name", ["tiny_conv", "tiny_dino"])
+def test_vggt_fp32_mode_matches_reference(golden_dir, name):
+    """PREC_BF16X3 everywhere: the mode that must meet the 1e-3 bar against the fp32 CPU reference."""
+    g, cfg, sd, images = _load(golden_dir, name)
+    m = vggt.VGGT(config=cfg, prec=PREC_BF16X3, head_prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    out = m(images.cuda(), want={"camera", "depth", "point"}, return_tokens=True)
+    torch.cuda.synchronize()
+    assert _maxerr(out["tokens_last"].cpu(), g["tokens_last"]) < 1e-3
+    assert _maxerr(torch.stack(out["pose_enc_list"]).cpu(), g["pose_enc_list"]) < 1e-3
+    assert _maxerr(out["pose_enc"].cpu(), g["pose_enc"]) < 1e-3
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
+        ref = g[k]
+        got = out[k].cpu().numpy()
+        assert got.shape == ref.shape
+        rel = np.abs(got - ref) / (np.abs(ref) + 1.0)
+        assert rel.max() < 1e-3, (k, rel.max())
+
+
+def test_vggt_bf16_mode_close_to_reference(golden_dir):
+    """PREC_BF16 aggregator (the reference's autocast mode) + fp32-accurate heads: documents the
+    cost of bf16 operands against the fp32 CPU reference."""
+    g, cfg, sd, images = _load(golden_dir, "tiny_conv")
+    m = vggt.VGGT(config=cfg, prec=PREC_BF16, head_prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    out = m(images.cuda(), want={"camera", "depth"}, return_tokens=True)
+    ref = g["tokens_last"]
+    rel = np.linalg.norm(out["tokens_last"].cpu().numpy() - ref) / np.linalg.norm(ref)
+    assert rel < 3e-2, rel
+    assert _maxerr(out["pose_enc"].cpu(), g["pose_enc"]) < 5e-2
+    d = out["depth"].cpu().numpy()
+    assert np.isfinite(d).all()
+    assert np.median(np.abs(d - g["depth"]) / (np.abs(g["depth"]) + 1.0)) < 3e-2
+
+
+def test_vggt_batched_time_steps_match_single(golden_dir):
+    """B > 1 (several time steps per call) gives the same per-step result as B = 1."""
+    g, cfg, sd, images = _load(golden_dir, "tiny_conv")
+    m = vggt.VGGT(config=cfg, prec=PREC_BF16X3, head_prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    im2 = W.make_images(int(g["S"]), int(g["H"]), int(g["W"]), seed=77)
+    both = torch.stack([images, im2]).cuda()
+    o2 = m(both, want={"camera", "depth"})
+    o1 = m(im2.cuda(), want={"camera", "depth"})
+    assert _maxerr(o2["pose_enc"][1].cpu(), o1["pose_enc"][0].cpu()) < 1e-4
+    assert _maxerr(o2["pose_enc"][0].cpu(), g["pose_enc"][0]) < 1e-3
+    assert _maxerr(o2["depth"][1].cpu(), o1["depth"][0].cpu()) < 1e-3
+
+
+def test_vggt_shape_errors(golden_dir):
+    from skiing_analysis_pytorch_amd import _lib
+
+    g, cfg, sd, images = _load(golden_dir, "tiny_conv")
+    m = vggt.VGGT(config=cfg, prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 4, 140, 140, device="cuda"))
+    with pytest.raises(_lib.SkimiError, match="not a multiple of patch"):
+        m(torch.zeros(2, 3, 141, 140, device="cuda"))
+    # missing weight -> strict load error
+    sd2 = dict(sd)
+    sd2.pop("camera_head.token_norm.weight")
+    with pytest.raises(RuntimeError):
+        vggt.VGGT(config=cfg).load_state_dict(sd2)
