@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""bench.py — 3D-pose frames/sec of the MI355X-native multi-view hot path.
+
+One "step" = one pass of the hot path over one batch of synthetic input: B time steps of an
+8-view 518x518 clip through the HIP VGGT forward (DINOv2 patch embed, 24 x {frame, global}
+attention, camera + depth + point heads — everything `preds = self.vggt(imgs)` computes,
+vggt/vggt/infer.py:84).  1 frame = one S-view time step.  Inputs are resident in HBM when the
+timed region starts.  Launched by the driver as
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One rank per GPU; time steps are independent, so ranks shard them with no data-path collective
+(weak scaling); the barrier + MAX-over-ranks timing is the only communication.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+S_VIEWS, IMG = 8, 518
+
+
+def vggt_flops_per_step(S):
+    """algorithmic FLOPs of one S-view call without the track head."""
+    return S * (1017.1 + 1015.5 + 829.9 + 1.7 + 298.5 + 298.6) * 1e9 + 24 * 4 * (S * 1374) ** 2 * 1024
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="time steps per call (B)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-views", type=int, default=2, help="views of the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from skiing_analysis_pytorch_amd import _lib, vggt, weights as W
+    from skiing_analysis_pytorch_amd._lib import PREC_BF16, PREC_BF16X3
+
+    cfg = W.VGGTConfig()   # VGGT-1B, the reference's VGGT()
+    model = vggt.VGGT(config=cfg, prec=PREC_BF16, head_prec=PREC_BF16X3)
+    sd = W.make_vggt_state_dict(cfg, seed=0, device=dev)      # random-init weights of that architecture
+    model.load_state_dict(sd)
+    cpu_sd = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu_sd = {k: v.cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.rand((B, S_VIEWS, 3, IMG, IMG), generator=g, device=dev, dtype=torch.float32)
+    want = {"camera", "depth", "point"}
+
+    def step():
+        return model(images, want=want)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    lib = _lib.lib()
+    # roofline leg: bracket every global-attention launch (seq = S*1374) of the timed region
+    seq_global = S_VIEWS * 1374
+    _lib.check(lib.skimi_profile_start(1, seq_global), "profile_start")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    _lib.check(lib.skimi_profile_stop(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "profile_stop")
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out["pose_enc"]).all()
+
+    frames = world * args.steps * B
+    value = frames / elapsed
+    line = {
+        "metric": "3D-pose frames/sec, 8-view 518px clips",
+        "value": value,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": "VGGT-1B multi_view_process step: 8 views x 518x518, camera+depth+point heads",
+                   "views": S_VIEWS, "image": IMG, "time_steps_per_call": B, "parallelism": f"clip-dp{world}",
+                   "aggregator_prec": "bf16 MFMA, fp32 accumulate/residual/LayerNorm/softmax",
+                   "head_prec": "bf16x3 (fp32-accurate)"},
+        "whole_path_tflops": vggt_flops_per_step(S_VIEWS) * B * args.steps * world / elapsed / 1e12,
+    }
+    if n.value > 0:
+        avg_s = ms.value * 1e-3 / n.value
+        flops_per_launch = fl.value / n.value
+        ach = flops_per_launch / avg_s / 1e12
+        line["roofline"] = {"kernel": "attn_bf16_kernel (global attention, seq 10992, 16 heads x 64)",
+                            "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                            "avg_launch_us": avg_s * 1e6, "launches": int(n.value),
+                            "flops_per_launch": flops_per_launch}
+    if rank == 0 and cpu_sd is not None:
+        line["cpu_baseline"] = cpu_baseline(cpu_sd, cfg, args.cpu_views)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cpu_sd, cfg, views):
+    """The oracle (fp32 CPU restatement of the reference, oracle/vggt_oracle.py) on a bounded
+    sample: ONE `views`-view 518x518 step on this host's cores.  An 8-view step costs
+    flops(8)/flops(views) more; the value is scaled by that ratio and the sample says so."""
+    from oracle import vggt_oracle
+
+    # cores actually granted to this process (the GPU box gives a 1-GPU job a 16-core share;
+    # os.cpu_count() reports the whole host and oversubscribes)
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, int(os.environ.get("SKIMI_CPU_THREADS", "16"))))
+    torch.set_num_threads(threads)
+    img = torch.rand((1, views, 3, IMG, IMG), generator=torch.Generator().manual_seed(5))
+    d = cfg.to_dict()
+    d["enable_track"] = False
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        vggt_oracle.vggt_forward(cpu_sd, img, d)
+        dt = time.perf_counter() - t0
+    ratio = vggt_flops_per_step(S_VIEWS) / vggt_flops_per_step(views)
+    return {"value": 1.0 / (dt * ratio), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"one {views}-view 518x518 step = {dt:.1f} s measured; 8-view step = x{ratio:.2f} FLOPs (extrapolated)",
+            "measured_seconds": dt}
+
+
+if __name__ == "__main__":
+    main()

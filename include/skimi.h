@@ -64,6 +64,14 @@ int skimi_version(void);
 /* number of HIP devices visible; does not initialise a context on any */
 int skimi_device_count(void);
 
+/* Measurement hook (bench.py roofline leg): while armed, every launch of the given kernel
+ * kind (1 = bf16 flash attention with seq_k >= min_size, 2 = MFMA contraction with
+ * M >= min_size) is bracketed by a hipEvent pair on its own stream.  skimi_profile_stop
+ * synchronises those events and returns the summed device time, the launch count and the
+ * algorithmic FLOPs / bytes of the bracketed launches. */
+int skimi_profile_start(int32_t kind, int64_t min_size);
+int skimi_profile_stop(double* total_ms, int64_t* launches, double* flops, double* bytes);
+
 /* ------------------------------------------------------------------------- */
 /* Generic fused contraction  out = epilogue( gather(A) . W^T )               */
 /* Replaces torch.nn.Linear / Conv1d / Conv2d / ConvTranspose2d(k==s) on the  */

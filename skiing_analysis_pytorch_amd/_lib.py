@@ -58,6 +58,9 @@ _SIGNATURES = {
     "skimi_last_error": (C.c_char_p, []),
     "skimi_version": (C.c_int, []),
     "skimi_device_count": (C.c_int, []),
+    "skimi_profile_start": (C.c_int, [C.c_int32, C.c_int64]),
+    "skimi_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double)]),
     "skimi_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "skimi_layernorm": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, C.c_float, _vp,
                                   C.c_int32, C.c_int64, _vp]),
@@ -98,6 +101,10 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python -m skiing_analysis_pytorch_amd.build` "
             "(or __graft_entry__.build()). There is no fallback path."
         )
+    # torch ships its own libamdhip64; load it first so libskimi binds to the SAME HIP runtime
+    # instance (streams and device pointers are shared with torch tensors).
+    import torch  # noqa: F401
+
     handle = C.CDLL(str(LIB_PATH))
     for name, (res, args) in _SIGNATURES.items():
         try:

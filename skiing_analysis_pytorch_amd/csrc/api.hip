@@ -1,6 +1,8 @@
 // C-ABI surface of libskimi.so: error channel, version, generic ops.
 #include <stdarg.h>
 
+#include <vector>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -13,6 +15,35 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+struct ProfState {
+    int kind = PROF_NONE;
+    long min_key = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double flops = 0, bytes = 0;
+    hipEvent_t pending = nullptr;
+};
+static ProfState g_prof;
+
+bool prof_armed(int kind, long size_key) { return g_prof.kind == kind && size_key >= g_prof.min_key; }
+void prof_before(hipStream_t st) {
+    std::pair<hipEvent_t, hipEvent_t> e;
+    if (!g_prof.pool.empty()) {
+        e = g_prof.pool.back();
+        g_prof.pool.pop_back();
+    } else {
+        (void)hipEventCreate(&e.first);
+        (void)hipEventCreate(&e.second);
+    }
+    (void)hipEventRecord(e.first, st);
+    g_prof.ev.push_back(e);
+}
+void prof_after(hipStream_t st, double flops, double bytes) {
+    (void)hipEventRecord(g_prof.ev.back().second, st);
+    g_prof.flops += flops;
+    g_prof.bytes += bytes;
 }
 
 }  // namespace skimi
@@ -29,6 +60,34 @@ int skimi_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int skimi_profile_start(int32_t kind, int64_t min_size) {
+    SKIMI_CHECK_ARG(kind == PROF_ATTN_BF16 || kind == PROF_GEMM, "skimi_profile_start: unknown kernel kind %d", kind);
+    for (auto& e : g_prof.ev) g_prof.pool.push_back(e);
+    g_prof.ev.clear();
+    g_prof.flops = g_prof.bytes = 0;
+    g_prof.kind = kind;
+    g_prof.min_key = min_size;
+    return SKIMI_OK;
+}
+
+int skimi_profile_stop(double* total_ms, int64_t* launches, double* flops, double* bytes) {
+    double ms = 0;
+    for (auto& e : g_prof.ev) {
+        SKIMI_HIP(hipEventSynchronize(e.second));
+        float t = 0;
+        SKIMI_HIP(hipEventElapsedTime(&t, e.first, e.second));
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int64_t)g_prof.ev.size();
+    if (flops) *flops = g_prof.flops;
+    if (bytes) *bytes = g_prof.bytes;
+    for (auto& e : g_prof.ev) g_prof.pool.push_back(e);
+    g_prof.ev.clear();
+    g_prof.kind = PROF_NONE;
+    return SKIMI_OK;
 }
 
 int skimi_gemm(const skimi_gemm_desc* d, void* stream) {

@@ -226,7 +226,14 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
     const int nqb = (int)cdiv(a.seq_q, 128);
     const long nblk = (long)nqb * a.heads * a.batch;
     SKIMI_CHECK_ARG(nblk < (1l << 31), "skimi_attention: grid too large");
+    const bool prof = prof_armed(PROF_ATTN_BF16, a.seq_k);
+    if (prof) prof_before(st);
     hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb);
+    if (prof) {
+        const double bh = (double)a.batch * a.heads;
+        prof_after(st, 4.0 * bh * a.seq_q * (double)a.seq_k * 64.0,
+                   2.0 * bh * 64.0 * (2.0 * a.seq_q + 2.0 * a.seq_k));
+    }
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }

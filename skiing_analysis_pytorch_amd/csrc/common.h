@@ -40,6 +40,13 @@ void set_error(const char* fmt, ...);
         }                                                                                \
     } while (0)
 
+// Optional in-library kernel timer (bench.py's roofline leg): when armed for a kernel kind,
+// every matching launch is bracketed by a hipEvent pair recorded on the launch stream.
+enum ProfKind { PROF_NONE = 0, PROF_ATTN_BF16 = 1, PROF_GEMM = 2 };
+bool prof_armed(int kind, long size_key);
+void prof_before(hipStream_t st);
+void prof_after(hipStream_t st, double flops, double bytes);
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

@@ -609,6 +609,8 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     }
 
     int rc;
+    const bool prof = prof_armed(PROF_GEMM, (long)d->M);
+    if (prof) prof_before(st);
     const bool af = d->a_dtype == SKIMI_F32, wf = d->w_dtype == SKIMI_F32;
 #define SKIMI_GO(BM_, BK_, NS_, TA_, TW_) rc = launch_cfg<BM_, BM_, BK_, NS_, TA_, TW_>(a, st)
     if (d->prec == SKIMI_PREC_BF16) {
@@ -634,6 +636,11 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
         }
     }
 #undef SKIMI_GO
+    if (prof) {
+        const double ea = af ? 4.0 : 2.0, ew = wf ? 4.0 : 2.0, eo = d->out_dtype == SKIMI_F32 ? 4.0 : 2.0;
+        prof_after(st, 2.0 * d->M * (double)d->N * d->K,
+                   ea * d->M * (double)d->K + ew * d->N * (double)d->K + eo * d->M * (double)d->N);
+    }
     if (rc != SKIMI_OK) return rc;
     if (splitk > 1) {
         long total = (long)d->M * d->N;

@@ -81,8 +81,11 @@ class VGGT:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            lib().skimi_vggt_destroy(h)
+        if h and lib is not None:   # module globals may already be torn down at interpreter exit
+            try:
+                lib().skimi_vggt_destroy(h)
+            except Exception:
+                pass
             self._h = None
 
     # ---- reference API --------------------------------------------------------------

@@ -62,8 +62,11 @@ class TemporalModel:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            lib().skimi_vp3d_destroy(h)
+        if h and lib is not None:   # module globals may already be torn down at interpreter exit
+            try:
+                lib().skimi_vp3d_destroy(h)
+            except Exception:
+                pass
             self._h = None
 
     # ---- reference API --------------------------------------------------------------
