@@ -1,0 +1,188 @@
+// GemmArgs + the shared fused epilogue (bias, activation, LayerScale, residuals, row remaps,
+// fp32/bf16 stores) of the MFMA contraction kernels in gemm.hip and gemm256.hip.
+#pragma once
+#include "common.h"
+
+namespace skimi {
+
+struct GemmArgs {
+    int M, N, K;
+    const void* A;
+    const void* W;
+    long lda, ldw;
+    int a_mode;
+    int cN, cH, cW, cC, KH, KW, stride, pad, dil, OH, OW;
+    const float* bias;
+    const float* gamma;
+    const void* resid;     // f32 or bf16 (resid_dtype)
+    int resid_dtype;
+    long ldr;
+    int resid_rpb;
+    long resid_bs;
+    long resid_off;
+    const void* resid2;    // second residual (same dtype), plain row m
+    long ldr2;
+    int out_rpb;           // output row remap (store_mode 0), like the residual's
+    long out_bs;
+    long out_off;
+    int act;
+    int post_act;          // activation applied after the residual adds
+    void* out;
+    void* out2;
+    int out_dtype;
+    long ldo, ldo2;
+    int store_mode, ps_s, ps_C;
+    // split-K
+    int splitk;
+    int k_per_split;   // multiple of BK
+    float* partial;    // [M, N] fp32, zeroed
+    int ntm, ntn;
+    int vec4;          // epilogue may use 16-B accesses (N, ld*, pointers all 4-element aligned)
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case SKIMI_ACT_RELU: return fmaxf(v, 0.f);
+        case SKIMI_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case SKIMI_ACT_SILU: return v / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float load_res(const void* r, int dt, long i) {
+    return dt == SKIMI_F32 ? ((const float*)r)[i] : bf2f(((const unsigned short*)r)[i]);
+}
+__device__ __forceinline__ float4 load_res4(const void* r, int dt, long i) {
+    if (dt == SKIMI_F32) return *reinterpret_cast<const float4*>((const float*)r + i);
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>((const unsigned short*)r + i);
+    return make_float4(bf2f((unsigned short)v[0]), bf2f((unsigned short)v[1]), bf2f((unsigned short)v[2]),
+                       bf2f((unsigned short)v[3]));
+}
+
+// everything that depends only on the output row m
+struct RowMap {
+    long out_off;   // mode 0: row*ldo; mode 1: top-left output pixel index of this input pixel
+    long out2_off;  // same for out2
+    long res_off;
+    long res2_off;
+};
+
+__device__ __forceinline__ RowMap row_map(const GemmArgs& p, int m) {
+    RowMap r;
+    if (p.store_mode == 0) {
+        long mo = m;
+        if (p.out_rpb > 0) {
+            int b = m / p.out_rpb;
+            mo = (long)b * p.out_bs + (m - b * p.out_rpb);
+        }
+        mo += p.out_off;
+        r.out_off = mo * p.ldo;
+        r.out2_off = mo * p.ldo2;
+    } else {
+        // m = (img, iy, ix) over [cN, cH, cW]
+        int hw = p.cH * p.cW;
+        int img = m / hw;
+        int rem = m - img * hw;
+        int iy = rem / p.cW;
+        int ix = rem - iy * p.cW;
+        long OWs = (long)p.cW * p.ps_s;
+        r.out_off = (((long)img * p.cH * p.ps_s + (long)iy * p.ps_s) * OWs + (long)ix * p.ps_s);
+        r.out2_off = r.out_off;
+    }
+    long mr = m;
+    if (p.resid_rpb > 0) {
+        int b = m / p.resid_rpb;
+        mr = (long)b * p.resid_bs + (m - b * p.resid_rpb);
+    }
+    r.res_off = (mr + p.resid_off) * p.ldr;
+    r.res2_off = (long)m * p.ldr2;
+    return r;
+}
+
+__device__ __forceinline__ void store_one(const GemmArgs& p, const RowMap& rm, int n, float acc) {
+    float v = acc;
+    if (p.bias) v += p.bias[n];
+    v = apply_act(v, p.act);
+    if (p.gamma) v *= p.gamma[n];
+    if (p.resid) v += load_res(p.resid, p.resid_dtype, rm.res_off + n);
+    if (p.resid2) v += load_res(p.resid2, p.resid_dtype, rm.res2_off + n);
+    v = apply_act(v, p.post_act);
+    long o, o2;
+    if (p.store_mode == 0) {
+        o = rm.out_off + n;
+        o2 = rm.out2_off + n;
+    } else {
+        int ab = n / p.ps_C;
+        int co = n - ab * p.ps_C;
+        int a = ab / p.ps_s;
+        int b = ab - a * p.ps_s;
+        long OWs = (long)p.cW * p.ps_s;
+        long pix = rm.out_off + (long)a * OWs + b;
+        o = pix * p.ldo + co;
+        o2 = pix * p.ldo2 + co;
+    }
+    if (p.out_dtype == SKIMI_F32) {
+        ((float*)p.out)[o] = v;
+        if (p.out2) ((unsigned short*)p.out2)[o2] = f2bf(v);
+    } else {
+        ((unsigned short*)p.out)[o] = f2bf(v);
+        if (p.out2) ((float*)p.out2)[o2] = v;
+    }
+}
+
+// four consecutive columns n..n+3 of one row (vectorised epilogue)
+__device__ __forceinline__ void store_four(const GemmArgs& p, const RowMap& rm, int n, float4 acc) {
+    float v[4] = {acc.x, acc.y, acc.z, acc.w};
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], p.act);
+    if (p.gamma) {
+        const float4 g = *reinterpret_cast<const float4*>(p.gamma + n);
+        v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+    }
+    if (p.resid) {
+        const float4 r = load_res4(p.resid, p.resid_dtype, rm.res_off + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    if (p.resid2) {
+        const float4 r = load_res4(p.resid2, p.resid_dtype, rm.res2_off + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    if (p.post_act != SKIMI_ACT_NONE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = apply_act(v[k], p.post_act);
+    }
+    long o, o2;
+    if (p.store_mode == 0) {
+        o = rm.out_off + n;
+        o2 = rm.out2_off + n;
+    } else {
+        int ab = n / p.ps_C;
+        int co = n - ab * p.ps_C;
+        int a = ab / p.ps_s;
+        int b = ab - a * p.ps_s;
+        long OWs = (long)p.cW * p.ps_s;
+        long pix = rm.out_off + (long)a * OWs + b;
+        o = pix * p.ldo + co;
+        o2 = pix * p.ldo2 + co;
+    }
+    bf16x4 hb;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hb[k] = (short)f2bf(v[k]);
+    const float4 fv = make_float4(v[0], v[1], v[2], v[3]);
+    if (p.out_dtype == SKIMI_F32) {
+        *reinterpret_cast<float4*>((float*)p.out + o) = fv;
+        if (p.out2) *reinterpret_cast<bf16x4*>((unsigned short*)p.out2 + o2) = hb;
+    } else {
+        *reinterpret_cast<bf16x4*>((unsigned short*)p.out + o) = hb;
+        if (p.out2) *reinterpret_cast<float4*>((float*)p.out2 + o2) = fv;
+    }
+}
+
+bool gemm256_eligible(const skimi_gemm_desc* d);
+int gemm256_launch(GemmArgs& a, hipStream_t st);
+
+}  // namespace skimi

@@ -206,3 +206,20 @@ def test_attention_bf16_online_softmax_rescale():
     x = qkv.float().cpu()
     ref = F.scaled_dot_product_attention(x[None, None, :, :64], x[None, None, :, 64:128], x[None, None, :, 128:])[0, 0]
     assert (out.float().cpu() - ref).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 64), (2100, 768, 1024), (10992, 1024, 4096)])
+def test_gemm256_lds_dma_path(M, N, K):
+    """bf16 x bf16 plain-row shapes with M >= 2048 take the 256x256 LDS-DMA kernel."""
+    a = (_rand(M, K, seed=70)).to(torch.bfloat16)
+    w = (_rand(N, K, seed=71, scale=1 / math.sqrt(K))).to(torch.bfloat16)
+    b, g, r = _rand(N, seed=72), _rand(N, seed=73), _rand(M, N, seed=74)
+    ref = a.float() @ w.float().T
+    out = ops.gemm(a, w, prec=PREC_BF16, bias=b, act=ACT_GELU, out_dtype=torch.bfloat16)
+    assert _rel(out.float(), F.gelu(ref + b)) < 1e-2
+    out = ops.gemm(a, w, prec=PREC_BF16, bias=b, gamma=g, resid=r)
+    assert _rel(out, r + g * (ref + b)) < 1e-5 + 2e-3
+    # exact integer data: any fragment / swizzle / row-map error shows as a wrong integer
+    ai = ((torch.arange(M * K, device=DEV).reshape(M, K) * 7 + 3) % 9 - 4).to(torch.bfloat16)
+    wi = ((torch.arange(N * K, device=DEV).reshape(N, K) * 5 + 1) % 7 - 3).to(torch.bfloat16)
+    assert torch.equal(ops.gemm(ai, wi, prec=PREC_BF16), ai.float() @ wi.float().T)
