@@ -58,6 +58,7 @@ extern "C" {
 #define SKIMI_ACT_RELU 1
 #define SKIMI_ACT_GELU 2   /* erf form, torch.nn.GELU() default (vggt/vggt/layers/mlp.py:26) */
 #define SKIMI_ACT_SILU 3
+#define SKIMI_ACT_SIGMOID 4
 
 const char* skimi_last_error(void);
 int skimi_version(void);

@@ -44,7 +44,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case SKIMI_ACT_RELU: return fmaxf(v, 0.f);
         case SKIMI_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        case SKIMI_ACT_SILU: return v / (1.f + __expf(-v));
+        case SKIMI_ACT_SILU: return v / (1.f + expf(-v));
+        case SKIMI_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         default: return v;
     }
 }

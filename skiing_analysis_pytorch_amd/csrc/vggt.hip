@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "track_kernels.h"
 #include "vggt_kernels.h"
 
 using namespace skimi;
@@ -81,6 +82,10 @@ struct Arena {
 
 struct UvTab { int w, h, C; float* tx; float* ty; };
 
+#define TRACK_PART 1
+#include "track_impl.inc"
+#undef TRACK_PART
+
 }  // namespace
 
 struct skimi_vggt {
@@ -98,6 +103,7 @@ struct skimi_vggt {
     LNw dino_norm;
     CamW cam;
     DptW depth, point, trackf;
+    TrackW track;
     // per-resolution tables (prepare())
     int prepH = 0, prepW = 0, prepF = 0;
     int* pos = nullptr;             // int32 [F*P, 2]
@@ -513,6 +519,10 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
     return nullptr;
 }
 
+#define TRACK_PART 2
+#include "track_impl.inc"
+#undef TRACK_PART
+
 // camera head (vggt/vggt/heads/camera_head.py:73-141), fp32 activations
 void run_camera(Ctx& c, const CamW& w, const float* sf, const float* sg, int B, int S, int P, int C, float* out_list,
                 float* out_last) {
@@ -653,7 +663,6 @@ int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query,
     const int nsp = 1 + cfg.num_register_tokens, P = nsp + np, F = B * S, M = F * P;
     const int prec = cfg.prec, adt = Ctx::act_dt(prec);
     const size_t es = Ctx::esz(adt);
-    (void)query; (void)nq;
 
     // split-K slab: large enough for the skinny camera-head / small-config GEMMs
     c.slab_bytes = std::max<size_t>((size_t)F * 6 * C * 4 * 4, 1u << 20);
@@ -666,8 +675,8 @@ int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query,
     const bool run_depth = cfg.enable_depth && out && (out->depth || out->depth_conf);
     const bool run_point = cfg.enable_point && out && (out->world_points || out->world_points_conf);
     const bool run_cam = cfg.enable_camera && out && (out->pose_enc || out->pose_enc_list);
-    const bool run_track = cfg.enable_track && out && out->track && query && nq > 0;
-    if (run_depth || run_point || run_track) for (int i = 0; i < 4; ++i) want(cfg.dpt_layers[i]);
+    const bool do_track = cfg.enable_track && out && out->track && query && nq > 0;
+    if (run_depth || run_point || do_track) for (int i = 0; i < 4; ++i) want(cfg.dpt_layers[i]);
     if (run_cam || (out && out->tokens_last)) want(cfg.depth - 1);
     std::map<int, std::pair<float*, float*>> saved;
     for (int l : keep) {
@@ -730,7 +739,7 @@ int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query,
     }
     float* sf[4];
     float* sg[4];
-    if (run_depth || run_point || run_track)
+    if (run_depth || run_point || do_track)
         for (int i = 0; i < 4; ++i) {
             sf[i] = saved[cfg.dpt_layers[i]].first;
             sg[i] = saved[cfg.dpt_layers[i]].second;
@@ -745,10 +754,7 @@ int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query,
         float* cf = out->world_points_conf ? out->world_points_conf : (float*)c.ar.alloc((size_t)F * H * W * 4);
         run_dpt(c, h->point, sf, sg, F, P, nsp, ph, pw, C, H, W, pts, cf, 1);
     }
-    if (run_track) {
-        set_error("skimi_vggt_forward: track head not built yet");
-        c.rc = SKIMI_ERR_STATE;
-    }
+    if (do_track) run_track(c, sf, sg, B, S, P, nsp, ph, pw, C, H, W, query, nq, out->track, out->vis, out->conf);
     return c.rc;
 }
 
@@ -882,11 +888,11 @@ int skimi_vggt_finalize(skimi_vggt* h) {
     }
     if (cfg.enable_point) h->point = pk.dpt("point_head", D, cfg.dpt_features, cfg.dpt_out_channels, 4, false, cfg.head_prec);
     if (cfg.enable_depth) h->depth = pk.dpt("depth_head", D, cfg.dpt_features, cfg.dpt_out_channels, 2, false, cfg.head_prec);
+    if (cfg.enable_track) pack_track(pk, h);
     if (pk.rc) return pk.rc;
     SKIMI_HIP(hipStreamSynchronize(pk.st));
-    // release the staged fp32 copies (track-head keys stay staged until that head is packed)
+    // release the staged fp32 copies
     for (auto it = h->raw.begin(); it != h->raw.end();) {
-        if (it->first.rfind("track_head.", 0) == 0) { ++it; continue; }
         (void)hipFree(it->second.first);
         it = h->raw.erase(it);
     }
@@ -917,8 +923,8 @@ size_t skimi_vggt_workspace_bytes(skimi_vggt* h, int32_t B, int32_t S, int32_t H
     float* one = (float*)(uintptr_t)16;
     all.pose_enc = all.pose_enc_list = all.depth = all.depth_conf = all.world_points = all.world_points_conf = one;
     all.tokens_last = one;
-    (void)n_query;
-    forward_impl(h, c, nullptr, nullptr, B, S, H, W, 0, &all);
+    if (n_query > 0) all.track = all.vis = all.conf = one;
+    forward_impl(h, c, nullptr, n_query > 0 ? one : nullptr, B, S, H, W, n_query, &all);
     return align_up(c.ar.peak, 256) + 256;
 }
 

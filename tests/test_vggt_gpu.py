@@ -89,3 +89,21 @@ def test_vggt_shape_errors(golden_dir):
     sd2.pop("camera_head.token_norm.weight")
     with pytest.raises(RuntimeError):
         vggt.VGGT(config=cfg).load_state_dict(sd2)
+
+
+def test_vggt_track_head_matches_reference(golden_dir):
+    """Track head (DPT features + CoTracker-style refinement) driven by query points."""
+    g, cfg, sd, images = _load(golden_dir, "tiny_conv")
+    m = vggt.VGGT(config=cfg, prec=PREC_BF16X3, head_prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    q = torch.from_numpy(g["query_points"]).cuda()
+    out = m(images.cuda(), query_points=q, want={"track"})
+    assert out["track"].shape == g["track"].shape
+    # Tolerance in pixels.  The refinement loop embeds the per-frame flow with frequencies up to
+    # 1000 rad/px (get_2d_embedding, track_modules/utils.py:107), so fp32 reassociation noise of
+    # 1e-5 px in iteration k re-enters iteration k+1 as 1e-2 rad: tracks agree to ~1e-2 px, not 1e-3.
+    assert _maxerr(out["track"].cpu(), g["track"]) < 5e-2
+    assert _maxerr(out["vis"].cpu(), g["vis"]) < 5e-3
+    assert _maxerr(out["conf"].cpu(), g["conf"]) < 5e-3
+    # the query frame keeps the query coordinates exactly (base_track_predictor.py:185-187)
+    assert torch.allclose(out["track"][0, 0].cpu(), torch.from_numpy(g["query_points"]), atol=1e-5)
