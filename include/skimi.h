@@ -241,6 +241,27 @@ int skimi_vggt_forward(skimi_vggt*, const float* images, const float* query_poin
                        int32_t H, int32_t W, int32_t n_query, const skimi_vggt_outputs* out,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* Geometry post-processing on device                                         */
+/* ------------------------------------------------------------------------- */
+/* pose_enc [rows, 9] (T, quat XYZW, fov_h, fov_w) -> extrinsic [rows, 3, 4] (cam-from-world,
+ * OpenCV) and intrinsic [rows, 3, 3] (may be NULL) for an H x W image.
+ * Replaces pose_encoding_to_extri_intri / quat_to_mat (vggt/vggt/utils/pose_enc.py:62-124,
+ * rotation.py:14-44). */
+int skimi_pose_to_cameras(const float* pose_enc, int64_t rows, int32_t H, int32_t W, float* extrinsic,
+                          float* intrinsic, void* stream);
+/* depth [frames, H, W] + cameras -> world points [frames, H, W, 3].
+ * Replaces unproject_depth_map_to_point_map (vggt/vggt/utils/geometry.py:15-117), which the
+ * reference runs in NumPy on the host after a D2H copy of the dense maps (infer.py:92-104). */
+int skimi_unproject_depth(const float* depth, const float* extrinsic, const float* intrinsic,
+                          float* world_points, int32_t frames, int32_t H, int32_t W, void* stream);
+/* DLT triangulation: K [steps, views, 3, 3], R [steps, views, 3, 3], t [steps, views, 3],
+ * keypoints [steps, views, joints, 2] pixels -> joints3d [steps, joints, 3].
+ * Replaces triangulate_point / triangulate_one_frame (vggt/triangulate.py:13-71) for
+ * views = 2 and generalises the same linear system to more views. */
+int skimi_triangulate_dlt(const float* K, const float* R, const float* t, const float* keypoints,
+                          float* joints3d, int64_t steps, int32_t views, int32_t joints, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

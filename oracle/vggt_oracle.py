@@ -521,3 +521,26 @@ def unproject_depth_map_to_point_map(depth, E, K):
         tc = -(Rc @ t[:, None])[:, 0]
         out.append(np.dot(cam, Rc.T) + tc)
     return np.stack(out, axis=0)
+
+
+def triangulate_point(P_list, x_list):
+    """vggt/triangulate.py:19-34 (DLT), written for V views: rows u*P[2]-P[0], v*P[2]-P[1] per view;
+    solution = last right-singular vector of A, dehomogenised.  V = 2 is the reference's function."""
+    A = []
+    for P, (u, v) in zip(P_list, x_list):
+        A.append(u * P[2] - P[0])
+        A.append(v * P[2] - P[1])
+    _, _, Vt = np.linalg.svd(np.stack(A, axis=0))
+    X = Vt[-1]
+    return (X / X[3])[:3]
+
+
+def triangulate_one_frame(K, R, T, kpts):
+    """vggt/triangulate.py:38-71 without the I/O: K, R [V,3,3], T [V,3], kpts [V,J,2] -> X3d [J,3] float32.
+    make_P = K @ [R | t] (triangulate.py:13-16)."""
+    Ps = [K[v] @ np.concatenate([R[v], T[v].reshape(3, 1)], axis=1) for v in range(K.shape[0])]
+    J = kpts.shape[1]
+    X3d = np.zeros((J, 3), dtype=np.float32)
+    for j in range(J):
+        X3d[j] = triangulate_point(Ps, [kpts[v, j] for v in range(K.shape[0])])
+    return X3d

@@ -75,6 +75,9 @@ _SIGNATURES = {
     "skimi_vp3d_receptive_field": (C.c_int32, [_vp]),
     "skimi_vp3d_workspace_bytes": (C.c_size_t, [_vp, C.c_int32, C.c_int32]),
     "skimi_vp3d_forward": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_size_t, _vp]),
+    "skimi_pose_to_cameras": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "skimi_unproject_depth": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "skimi_triangulate_dlt": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int32, _vp]),
     "skimi_vggt_create": (_vp, [_vp]),
     "skimi_vggt_destroy": (None, [_vp]),
     "skimi_vggt_set_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, C.c_int32]),

@@ -1,0 +1,198 @@
+"""Counterparts of the reference's VGGT entry points, with the same signatures and return values
+but none of the per-frame PNG / GLB / matplotlib I/O (out of scope: SURVEY §8):
+
+    load_and_preprocess_images        vggt/load.py:38-183
+    CameraHead                        vggt/vggt/infer.py:46-215   (run_vggt, reconstruct_from_frames, ...)
+    process_multi_view_clip           the hot loop of vggt/multi_view_process.py:133-309
+    process_single_view_clip          vggt/single_view_process.py:130-170
+
+The model call is the HIP VGGT (skiing_analysis_pytorch_amd.vggt.VGGT); pose decoding,
+depth unprojection and DLT triangulation also run on device (geometry.py); only the final small
+arrays cross to the host.  Time steps of a clip are independent, so under torch.distributed they
+are sharded across ranks and the per-step 3D joints are re-assembled with ONE all-gather
+(parallel.py).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import geometry, parallel
+from ._lib import PREC_BF16, PREC_BF16X3
+from .vggt import VGGT
+from .weights import VGGTConfig
+
+
+def load_and_preprocess_images(image_list: Sequence, mode: str = "crop") -> torch.Tensor:
+    """vggt/load.py:38-183.  image_list: HWC uint8 tensors / arrays.  Width -> 518 (bicubic, PIL),
+    height -> round(h*518/w/14)*14, centre-crop heights > 518 ("crop") or pad to 518x518 with
+    white ("pad").  Returns [N, 3, H, W] float32 in [0, 1] on the host."""
+    from PIL import Image
+
+    if len(image_list) == 0:
+        raise ValueError("At least 1 image is required")
+    if mode not in ["crop", "pad"]:
+        raise ValueError("Mode must be either 'crop' or 'pad'")
+    images, shapes = [], set()
+    target = 518
+    for im in image_list:
+        arr = im.numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
+        img = Image.fromarray(arr)
+        if img.mode == "RGBA":
+            bg = Image.new("RGBA", img.size, (255, 255, 255, 255))
+            img = Image.alpha_composite(bg, img)
+        img = img.convert("RGB")
+        width, height = img.size
+        if mode == "pad":
+            if width >= height:
+                new_w = target
+                new_h = round(height * (new_w / width) / 14) * 14
+            else:
+                new_h = target
+                new_w = round(width * (new_h / height) / 14) * 14
+        else:
+            new_w = target
+            new_h = round(height * (new_w / width) / 14) * 14
+        img = img.resize((new_w, new_h), Image.Resampling.BICUBIC)
+        t = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).to(torch.float32) / 255.0
+        if mode == "crop" and new_h > target:
+            y0 = (new_h - target) // 2
+            t = t[:, y0:y0 + target, :]
+        if mode == "pad":
+            hp, wp = target - t.shape[1], target - t.shape[2]
+            if hp > 0 or wp > 0:
+                t = torch.nn.functional.pad(t, (wp // 2, wp - wp // 2, hp // 2, hp - hp // 2), mode="constant", value=1.0)
+        shapes.add((t.shape[1], t.shape[2]))
+        images.append(t)
+    if len(shapes) > 1:
+        mh, mw = max(s[0] for s in shapes), max(s[1] for s in shapes)
+        padded = []
+        for t in images:
+            hp, wp = mh - t.shape[1], mw - t.shape[2]
+            if hp > 0 or wp > 0:
+                t = torch.nn.functional.pad(t, (wp // 2, wp - wp // 2, hp // 2, hp - hp // 2), mode="constant", value=1.0)
+            padded.append(t)
+        images = padded
+    return torch.stack(images)
+
+
+class CameraHead:
+    """Drop-in for vggt.vggt.infer.CameraHead (the reference-side VGGT wrapper)."""
+
+    def __init__(self, cfg=None, out_dir: Optional[Path] = None, model: Optional[VGGT] = None, state_dict=None,
+                 prec=PREC_BF16, head_prec=PREC_BF16X3):
+        gpu = 0
+        try:
+            gpu = int(cfg["infer"]["gpu"]) if cfg is not None else 0   # configs/vggt.yaml infer.gpu
+        except (KeyError, TypeError):
+            gpu = 0
+        if not torch.cuda.is_available():
+            raise RuntimeError("VGGT needs a GPU.")   # infer.py:49-51
+        self.device = f"cuda:{gpu}"
+        torch.cuda.set_device(gpu)
+        self.outdir = Path(out_dir) if out_dir is not None else None
+        # the reference reads these two at the ROOT of the config (infer.py:56-57)
+        self.conf_thres = cfg.get("conf_thres", 50.0) if hasattr(cfg, "get") else 50.0
+        self.prediction_mode = cfg.get("prediction_mode", "All") if hasattr(cfg, "get") else "All"
+        self.vggt = model if model is not None else self.load_vggt_model(self.device, state_dict=state_dict, prec=prec,
+                                                                        head_prec=head_prec)
+
+    @staticmethod
+    def load_vggt_model(device="cuda", verbose=True, state_dict=None, ckpt_path=None, prec=PREC_BF16,
+                        head_prec=PREC_BF16X3):
+        """infer.py:59-69 fetches model.pt from a URL; offline, pass the same flat state_dict
+        (or a local path to it)."""
+        model = VGGT(prec=prec, head_prec=head_prec)
+        if state_dict is None:
+            if ckpt_path is None:
+                raise RuntimeError("no network here: pass state_dict= or ckpt_path= (the reference's model.pt format)")
+            state_dict = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        model.load_state_dict(state_dict)
+        return model.eval()
+
+    @torch.no_grad()
+    def run_vggt(self, images: List[torch.Tensor], to_numpy: bool = True):
+        """infer.py:71-105.  Returns (out dict, H, W).  With to_numpy=False everything stays in HBM."""
+        imgs = load_and_preprocess_images(images).to(self.device)
+        preds = self.vggt(imgs)
+        H, W = imgs.shape[-2:]
+        E, K = geometry.pose_encoding_to_extri_intri(preds["pose_enc"], (H, W))
+        preds["extrinsic"], preds["intrinsic"] = E, K
+        preds["world_points_from_depth"] = geometry.unproject_depth_map_to_point_map(
+            preds["depth"][0], E[0], K[0])[None]
+        if not to_numpy:
+            return preds, H, W
+        out = {k: (v.detach().cpu().numpy().squeeze(0) if isinstance(v, torch.Tensor) else v) for k, v in preds.items()}
+        out["pose_enc_list"] = None
+        return out, H, W
+
+    extrinsic_to_RT = staticmethod(geometry.extrinsic_to_RT)
+    scale_intrinsics = staticmethod(geometry.scale_intrinsics)
+
+    def reconstruct_from_frames(self, frame_id: int, imgs: List[torch.Tensor]):
+        """infer.py:157-215 -> (extrinsics [S,3,4], intrinsics rescaled to the source resolution
+        (list of [3,3]), R [S,3,3], t [S,3], C [S,3], world_points_from_depth)."""
+        H, W = imgs[0].shape[:2]
+        preds, orig_h, orig_w = self.run_vggt(imgs)
+        E, K = preds["extrinsic"], preds["intrinsic"]
+        R, t, C = self.extrinsic_to_RT(E)
+        K_resized = [self.scale_intrinsics(K[i], orig_size=(orig_h, orig_w), new_size=(H, W)) for i in range(len(K))]
+        if self.outdir is not None:
+            d = self.outdir / f"frame_{frame_id:04d}"
+            d.mkdir(parents=True, exist_ok=True)
+            np.savez(d / "predictions.npz", extrinsic=E, intrinsic=K, pose_enc=preds["pose_enc"])
+        return E, K_resized, R, t, C, preds["world_points_from_depth"]
+
+
+def save_camera_info(out_pt_path: Path, all_frame_camera_intrinsics, all_frame_R, all_frame_t, all_frame_C,
+                     all_frame_x3d=None):
+    """vggt/save.py:84-110 (NPZ with camera_intrinsics [N,C,3,3], R [N,C,3,3], t [N,C,3], C [N,C,3]);
+    accepts the all_frame_x3d the reference's caller passes (multi_view_process.py:312-319)."""
+    data = {"camera_intrinsics": np.stack(all_frame_camera_intrinsics, axis=0), "R": np.stack(all_frame_R, axis=0),
+            "t": np.stack(all_frame_t, axis=0), "C": np.stack(all_frame_C, axis=0)}
+    if all_frame_x3d is not None:
+        data["x3d"] = np.stack(all_frame_x3d, axis=0)
+    np.savez_compressed(Path(out_pt_path).with_suffix(".npz"), **data)
+
+
+@torch.no_grad()
+def process_multi_view_clip(model: VGGT, frames: torch.Tensor, keypoints: torch.Tensor, steps_per_call: int = 4,
+                            want_dense: bool = False) -> Dict[str, torch.Tensor]:
+    """The hot loop of process_multi_view_video (vggt/multi_view_process.py:133-309) for a clip
+    already in memory: frames [T, S, 3, H, W] in [0,1] (device), keypoints [T, S, J, 2] in the
+    pixels of the H x W frames.  Per time step: one S-view VGGT call -> cameras -> DLT
+    triangulation of the J joints over the S views.
+
+    Under torch.distributed the T time steps are split in contiguous blocks across ranks and the
+    [T, J, 3] joints (+ cameras) are re-assembled on every rank with one all-gather."""
+    T, S = frames.shape[:2]
+    H, W = frames.shape[-2:]
+    lo, hi, T_pad = parallel.shard_range(T)
+    joints, Es, Ks = [], [], []
+    want = {"camera", "depth", "point"} if want_dense else {"camera"}
+    for a in range(lo, hi, steps_per_call):
+        b = min(a + steps_per_call, hi)
+        idx = [min(i, T - 1) for i in range(a, b)]          # padded steps repeat the last one
+        out = model(frames[idx], want=want)
+        E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (H, W))
+        R, t = E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous()
+        joints.append(geometry.triangulate_joints(K, R, t, keypoints[idx]))
+        Es.append(E)
+        Ks.append(K)
+    joints, Es, Ks = torch.cat(joints), torch.cat(Es), torch.cat(Ks)
+    return {"joints3d": parallel.all_gather_steps(joints, T), "extrinsic": parallel.all_gather_steps(Es, T),
+            "intrinsic": parallel.all_gather_steps(Ks, T)}
+
+
+@torch.no_grad()
+def process_single_view_clip(model: VGGT, frames: torch.Tensor, every: int = 30):
+    """vggt/single_view_process.py:130-170: every `every`-th frame of ONE camera forms a single
+    S = ceil(T/every) call; returns the cameras of those frames.  frames [T, 3, H, W] (device)."""
+    sel = frames[::every]
+    H, W = sel.shape[-2:]
+    out = model(sel, want={"camera"})
+    E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (H, W))
+    return {"extrinsic": E[0], "intrinsic": K[0], "pose_enc": out["pose_enc"][0]}

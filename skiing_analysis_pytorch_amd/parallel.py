@@ -1,0 +1,39 @@
+"""Clip-level data parallelism: one process per GPU, time steps sharded in contiguous blocks,
+ONE all-gather to re-assemble the per-step outputs (RCCL over xGMI: `backend="nccl"` is RCCL on
+ROCm; `gloo` on CPU for the tests).
+
+The reference's only multi-GPU mechanism is a thread pool that hands whole videos to free GPUs
+(prepare_side_results/main.py:20-55); time steps of one clip are just as independent
+(vggt/multi_view_process.py:133 loops over them), so they shard with no data-path collective.
+Payload of the gather: [T/W, 17, 3] fp32 + cameras — tens of KB, latency-bound, one hop.
+If W does not divide T the last rank's block is padded by repeating the last step and the pad
+is dropped after the gather, which keeps the collective uniform."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_range(T: int, rank: int = None, world_size: int = None):
+    """-> (lo, hi, T_pad): this rank owns padded steps [lo, hi); per-rank block = T_pad / W."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    per = (T + world_size - 1) // world_size
+    return rank * per, (rank + 1) * per, per * world_size
+
+
+def all_gather_steps(local: torch.Tensor, T: int) -> torch.Tensor:
+    """local: this rank's [T_pad/W, ...] block -> [T, ...] on every rank (pad dropped)."""
+    rank, world_size = world()
+    if world_size == 1:
+        return local[:T]
+    local = local.contiguous()
+    out = torch.empty((world_size * local.shape[0], *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out[:T]

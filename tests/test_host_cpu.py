@@ -1,0 +1,101 @@
+"""CPU: host-side logic — fusion / EMA vs the reference's own outputs, time-step sharding and the
+all-gather re-assembly under torch.distributed (gloo, world_size 2), image preprocessing."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from skiing_analysis_pytorch_amd import fuse, parallel
+
+
+def test_fuse_and_ema_match_reference(golden_dir):
+    g = np.load(golden_dir / "fuse_ema.npz")
+    ids = [int(i) for i in g["ids"]]
+    L, R = g["L"], g["R"]
+    T = L.shape[0]
+    fused = np.stack([fuse.fuse_frame_3d(L[t], R[t], g["ql"][t], g["qr"][t]) for t in range(T)])
+    # NaN pattern (missing joints) is an index path: bit-exact; values: same float64 arithmetic
+    assert np.array_equal(np.isnan(fused), np.isnan(g["fused"]))
+    np.testing.assert_array_equal(np.nan_to_num(fused), np.nan_to_num(g["fused"]))
+    for name, kw in (("adaptive", {}), ("plain", dict(adaptive=False, alpha=0.6))):
+        Y = fuse.temporal_smooth_ema(fused, ids, **kw)
+        assert np.array_equal(np.isnan(Y), np.isnan(g["smooth_" + name]))
+        np.testing.assert_array_equal(np.nan_to_num(Y), np.nan_to_num(g["smooth_" + name]))
+    # dict round trip
+    d = fuse.to_dicts(fused, ids)
+    np.testing.assert_array_equal(np.nan_to_num(fuse.from_dicts(d, ids)), np.nan_to_num(fused))
+    assert fuse.temporal_smooth_ema(np.zeros((0, 3, 3))).shape == (0, 3, 3)   # empty clip
+
+
+def test_shard_range_covers_all_steps():
+    for T in (1, 7, 8, 64, 65):
+        for W in (1, 2, 4, 8):
+            seen = []
+            for r in range(W):
+                lo, hi, tp = parallel.shard_range(T, r, W)
+                assert hi - lo == tp // W
+                seen += list(range(lo, hi))
+            assert seen == list(range(tp)) and tp >= T and tp - T < W
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, T, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi, _ = parallel.shard_range(T)
+        # each rank "computes" joints for its own (padded) steps: value = step index
+        idx = torch.tensor([min(i, T - 1) for i in range(lo, hi)], dtype=torch.float32)
+        local = idx[:, None, None].expand(-1, 17, 3).contiguous()
+        full = parallel.all_gather_steps(local, T)
+        q.put((rank, full[:, 0, 0].tolist(), tuple(full.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T", [8, 7])
+def test_all_gather_steps_gloo_world2(T):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, T, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, vals, shape in res:
+        assert shape == (T, 17, 3)
+        assert vals == [float(i) for i in range(T)]   # every rank holds the whole clip, pad dropped
+
+
+def test_load_and_preprocess_images_shapes():
+    from skiing_analysis_pytorch_amd.infer import load_and_preprocess_images
+
+    rng = np.random.default_rng(0)
+    imgs = [torch.from_numpy(rng.integers(0, 255, size=(1080, 1920, 3), dtype=np.uint8)) for _ in range(2)]
+    out = load_and_preprocess_images(imgs)
+    # width 518, height round(1080*518/1920/14)*14 = 294 (vggt/load.py:109-112)
+    assert out.shape == (2, 3, 294, 518) and out.dtype == torch.float32
+    assert 0.0 <= float(out.min()) and float(out.max()) <= 1.0
+    sq = load_and_preprocess_images([torch.zeros(518, 518, 3, dtype=torch.uint8)])
+    assert sq.shape == (1, 3, 518, 518)
+    tall = load_and_preprocess_images([torch.zeros(1200, 600, 3, dtype=torch.uint8)])
+    assert tall.shape == (1, 3, 518, 518)      # centre-cropped height
+    with pytest.raises(ValueError):
+        load_and_preprocess_images([])
+    with pytest.raises(ValueError):
+        load_and_preprocess_images(imgs, mode="stretch")

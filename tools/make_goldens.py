@@ -178,6 +178,53 @@ def gen_vggt_tiny():
 
 GENERATORS = {"vp3d": gen_vp3d, "vggt_tiny": gen_vggt_tiny}
 
+
+
+def gen_fuse():
+    """fuse/fuse.py (pure NumPy): fuse_frame_3d + temporal_smooth_ema on a synthetic MHR-70-id
+    sequence with missing joints (NaN) on either side."""
+    from fuse.fuse import fuse_frame_3d, temporal_smooth_ema
+
+    rng = np.random.default_rng(0)
+    ids = [1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 41, 62, 69, 20, 33]
+    T, J = 40, len(ids)
+    base = rng.normal(size=(1, J, 3))
+    L = base + np.cumsum(rng.normal(scale=0.03, size=(T, J, 3)), axis=0)
+    R = L + rng.normal(scale=0.02, size=(T, J, 3))
+    miss_l = rng.random((T, J)) < 0.08
+    miss_r = rng.random((T, J)) < 0.08
+    ql, qr = rng.normal(size=(T, J)), rng.normal(size=(T, J))
+    fused = np.full((T, J, 3), np.nan)
+    seq = []
+    for t in range(T):
+        dl = {jid: L[t, j] for j, jid in enumerate(ids) if not miss_l[t, j]}
+        dr = {jid: R[t, j] for j, jid in enumerate(ids) if not miss_r[t, j]}
+        if not dl:
+            dl = {ids[0]: L[t, 0]}
+        if not dr:
+            dr = {ids[0]: R[t, 0]}
+        f = fuse_frame_3d(dl, dr, ql[t], qr[t], ids)
+        seq.append(f)
+        for j, jid in enumerate(ids):
+            if jid in f:
+                fused[t, j] = f[jid]
+    out = {}
+    for name, kw in (("adaptive", dict()), ("plain", dict(adaptive=False, alpha=0.6))):
+        sm = temporal_smooth_ema(seq, ids, **kw)
+        Y = np.full((T, J, 3), np.nan)
+        for t in range(T):
+            for j, jid in enumerate(ids):
+                if jid in sm[t]:
+                    Y[t, j] = sm[t][jid]
+        out["smooth_" + name] = Y
+    np.savez_compressed(GOLD / "fuse_ema.npz", ids=np.array(ids), L=np.where(miss_l[..., None], np.nan, L),
+                        R=np.where(miss_r[..., None], np.nan, R), ql=ql, qr=qr, fused=fused, **out)
+    print("wrote fuse_ema.npz")
+
+
+GENERATORS["fuse"] = gen_fuse
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENERATORS)
     for w in which:
