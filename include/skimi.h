@@ -126,7 +126,18 @@ typedef struct skimi_gemm_desc {
     void* splitk_scratch;
     uint64_t splitk_scratch_bytes;
     int32_t force_splitk;
+    /* optional fast path of SKIMI_PREC_BF16X3 for large shapes: W_split = the same weights as two
+     * bf16 planes [hi | lo], each [N, ldw] (skimi_split_planes), and x3_scratch = caller-owned
+     * scratch of >= 4 bytes per element of the A buffer the launch touches, where A is split once
+     * and from where the four planes stream through LDS-DMA.  Both NULL = generic kernel. */
+    const void* W_split;
+    void* x3_scratch;
+    uint64_t x3_scratch_bytes;
 } skimi_gemm_desc;
+
+/* fp32 [rows, C] (row stride ld elements) -> bf16 planes hi[rows, C], lo[rows, C]:
+ * hi = bf16(x), lo = bf16(x - hi)  (operand form of SKIMI_PREC_BF16X3's fast path) */
+int skimi_split_planes(const float* x, int64_t ld, int64_t rows, int32_t C, void* hi, void* lo, void* stream);
 
 int skimi_gemm(const skimi_gemm_desc* d, void* stream);
 

@@ -49,6 +49,7 @@ class GemmDesc(C.Structure):
         ("splitk_scratch", C.c_void_p),
         ("splitk_scratch_bytes", C.c_uint64),
         ("force_splitk", C.c_int32),
+        ("W_split", C.c_void_p), ("x3_scratch", C.c_void_p), ("x3_scratch_bytes", C.c_uint64),
     ]
 
 
@@ -62,6 +63,7 @@ _SIGNATURES = {
     "skimi_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]),
     "skimi_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "skimi_split_planes": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp]),
     "skimi_layernorm": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, C.c_float, _vp,
                                   C.c_int32, C.c_int64, _vp]),
     "skimi_qknorm_rope": (C.c_int, [_vp, C.c_int32, C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, C.c_float,

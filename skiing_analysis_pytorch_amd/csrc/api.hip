@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "kernels.h"
 
 namespace skimi {
@@ -97,6 +98,11 @@ int skimi_gemm(const skimi_gemm_desc* d, void* stream) {
     }
     return gemm_dispatch(d, (hipStream_t)stream, d->splitk_scratch, (size_t)d->splitk_scratch_bytes,
                          d->force_splitk);
+}
+
+int skimi_split_planes(const float* x, int64_t ld, int64_t rows, int32_t C, void* hi, void* lo, void* stream) {
+    SKIMI_CHECK_ARG(x && hi && lo && rows > 0 && C > 0, "skimi_split_planes: bad arguments");
+    return split_planes_launch(x, (long)ld, (long)rows, C, hi, lo, (hipStream_t)stream);
 }
 
 int skimi_layernorm(const float* x, const float* x2, int64_t ldx, int64_t rows, int32_t C,

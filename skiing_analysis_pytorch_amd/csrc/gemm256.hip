@@ -11,6 +11,8 @@
 //     address and again on the ds_read_b128 (both sides or neither);
 //   * two-phase loop: issue tile t+1's DMA, MFMA tile t, vmcnt(0) + barrier;
 //   * epilogue through per-wave LDS slabs -> row-contiguous 16-B stores (shared with gemm.hip).
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -19,7 +21,9 @@ namespace skimi {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
-template <int MT>   // M tiles of 32 rows per wave: BM = 64 * MT (192 or 256)
+// EPI: 0 = generic epilogue (runtime flags); 1 = bias (+act) -> bf16 rows (qkv, fc1);
+//      2 = bias, LayerScale, fp32 residual -> fp32 rows, plain row map (proj, fc2)
+template <int MT, int EPI>   // M tiles of 32 rows per wave: BM = 64 * MT (192 or 256)
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     constexpr int BM = 64 * MT, BN = 256, BK = 64;
     constexpr int RB = 128;                    // LDS row bytes
@@ -84,29 +88,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+        if (kt + 1 < nkt && !(p.dbg & 1)) stage(cur ^ 1, kt + 1);
         const char* ab = smem + cur * BUF;
         const char* wb = ab + A_TILE;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 af[MT], wf[2];
+        // fragment reads are software-pipelined one k-step ahead of the MFMAs (two register sets,
+        // pinned by sched_barrier): the ds_read latency of step s+1 hides under step s's 8 MFMAs
+        bf16x8 af[2][MT], wf[2][2];
+        auto load_frags = [&](int s, int set) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row = wr * (32 * MT) + i * 32 + l31;
-                af[i] = *reinterpret_cast<const bf16x8*>(ab + row * RB + (((2 * s + lh) ^ ((row >> 1) & 7)) << 4));
+                af[set][i] = *reinterpret_cast<const bf16x8*>(ab + row * RB + (((2 * s + lh) ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = wc * 64 + j * 32 + l31;
-                wf[j] = *reinterpret_cast<const bf16x8*>(wb + row * RB + (((2 * s + lh) ^ ((row >> 1) & 7)) << 4));
+                wf[set][j] = *reinterpret_cast<const bf16x8*>(wb + row * RB + (((2 * s + lh) ^ ((row >> 1) & 7)) << 4));
             }
+        };
+        if (!(p.dbg & 2)) {
+        load_frags(0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // keep set 0's reads ahead of set 1's: counted lgkmcnt
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s + 1 < 4) load_frags(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], wf[s & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         }
         __syncthreads();
     }
@@ -124,24 +139,67 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         // needs to keep them in program order
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        if (EPI != 0) {
+            // straight-line fast path: all 8 row reads in flight, column constants hoisted
+            float4 v[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                v[it] = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + 4 * (lane & 15)]);
+            if (n < p.N) {
+                const float4 bs = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+                float4 gm = make_float4(1, 1, 1, 1);
+                if (EPI == 2) gm = *reinterpret_cast<const float4*>(p.gamma + n);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = m0 + wr * (32 * MT) + i * 32 + it * 4 + (lane >> 4);
+                    if (m < p.M) {
+                        float y0 = v[it].x + bs.x, y1 = v[it].y + bs.y, y2 = v[it].z + bs.z, y3 = v[it].w + bs.w;
+                        if (EPI == 1) {
+                            y0 = apply_act(y0, p.act); y1 = apply_act(y1, p.act);
+                            y2 = apply_act(y2, p.act); y3 = apply_act(y3, p.act);
+                            bf16x4 hb;
+                            hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
+                            *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)m * p.ldo + n) = hb;
+                        } else {
+                            const float4 r = *reinterpret_cast<const float4*>((const float*)p.resid + (long)m * p.ldr + n);
+                            *reinterpret_cast<float4*>((float*)p.out + (long)m * p.ldo + n) =
+                                make_float4(r.x + gm.x * y0, r.y + gm.y * y1, r.z + gm.z * y2, r.w + gm.w * y3);
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll 1
-        for (int it = 0; it < 8; ++it) {
-            const int row_l = it * 4 + (lane >> 4);
-            const int m = m0 + wr * (32 * MT) + i * 32 + row_l;
-            if (m >= p.M || n >= p.N) continue;
-            const float4 v = *reinterpret_cast<const float4*>(&stg[row_l * 64 + 4 * (lane & 15)]);
-            const RowMap rm = row_map(p, m);
-            if (p.vec4) {
-                store_four(p, rm, n, v);
-            } else {
-                store_one(p, rm, n, v.x);
-                if (n + 1 < p.N) store_one(p, rm, n + 1, v.y);
-                if (n + 2 < p.N) store_one(p, rm, n + 2, v.z);
-                if (n + 3 < p.N) store_one(p, rm, n + 3, v.w);
+            for (int it = 0; it < 8; ++it) {
+                const int row_l = it * 4 + (lane >> 4);
+                const int m = m0 + wr * (32 * MT) + i * 32 + row_l;
+                if (m >= p.M || n >= p.N) continue;
+                const float4 v = *reinterpret_cast<const float4*>(&stg[row_l * 64 + 4 * (lane & 15)]);
+                const RowMap rm = row_map(p, m);
+                if (p.vec4) {
+                    store_four(p, rm, n, v);
+                } else {
+                    store_one(p, rm, n, v.x);
+                    if (n + 1 < p.N) store_one(p, rm, n + 1, v.y);
+                    if (n + 2 < p.N) store_one(p, rm, n + 2, v.z);
+                    if (n + 3 < p.N) store_one(p, rm, n + 3, v.w);
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
+}
+
+// which compile-time epilogue serves this launch (0 = generic)
+static int epi_kind(const GemmArgs& a) {
+    const bool plain = a.vec4 && a.store_mode == 0 && a.out_rpb == 0 && a.out_off == 0 && a.out2 == nullptr &&
+                       a.resid2 == nullptr && a.post_act == SKIMI_ACT_NONE && a.N % 4 == 0;
+    if (!plain) return 0;
+    if (a.out_dtype == SKIMI_BF16 && a.gamma == nullptr && a.resid == nullptr) return 1;
+    if (a.out_dtype == SKIMI_F32 && a.gamma != nullptr && a.resid != nullptr && a.resid_dtype == SKIMI_F32 &&
+        a.resid_rpb == 0 && a.resid_off == 0 && a.act == SKIMI_ACT_NONE)
+        return 2;
+    return 0;
 }
 
 bool gemm256_eligible(const skimi_gemm_desc* d) {
@@ -150,12 +208,12 @@ bool gemm256_eligible(const skimi_gemm_desc* d) {
            d->N >= 512 && (((uintptr_t)d->A | (uintptr_t)d->W) & 15) == 0;
 }
 
-template <int MT>
+template <int MT, int EPI>
 static int launch256(GemmArgs& a, hipStream_t st) {
     constexpr size_t lds = 2ull * (64 * MT + 256) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<MT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<MT, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(gemm256) failed: %s", hipGetErrorString(e));
@@ -166,7 +224,7 @@ static int launch256(GemmArgs& a, hipStream_t st) {
     a.ntm = (int)cdiv(a.M, 64 * MT);
     a.ntn = (int)cdiv(a.N, 256);
     a.splitk = 1;
-    hipLaunchKernelGGL(gemm256_kernel<MT>, dim3(a.ntm * a.ntn), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((gemm256_kernel<MT, EPI>), dim3(a.ntm * a.ntn), dim3(512), lds, st, a);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }
@@ -174,12 +232,21 @@ static int launch256(GemmArgs& a, hipStream_t st) {
 // pick the tile height (192 or 256 rows) that wastes the fewest CU-rounds for this shape:
 // one workgroup per CU, so time ~ ceil(tiles / 256) * (rows per tile)
 int gemm256_launch(GemmArgs& a, hipStream_t st) {
+    static const int dbg = getenv("SKIMI_GEMM256_ABL") ? atoi(getenv("SKIMI_GEMM256_ABL")) : 0;
+    a.dbg = dbg;
     auto cost = [&](int bm) {
         const long tiles = cdiv(a.M, bm) * cdiv(a.N, 256);
         return (double)cdiv(tiles, 256) * bm;
     };
-    if (cost(192) < cost(256)) return launch256<3>(a, st);
-    return launch256<4>(a, st);
+    const int epi = epi_kind(a);
+    if (cost(192) < cost(256)) {
+        if (epi == 1) return launch256<3, 1>(a, st);
+        if (epi == 2) return launch256<3, 2>(a, st);
+        return launch256<3, 0>(a, st);
+    }
+    if (epi == 1) return launch256<4, 1>(a, st);
+    if (epi == 2) return launch256<4, 2>(a, st);
+    return launch256<4, 0>(a, st);
 }
 
 }  // namespace skimi

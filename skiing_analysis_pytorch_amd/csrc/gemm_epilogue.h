@@ -38,6 +38,7 @@ struct GemmArgs {
     float* partial;    // [M, N] fp32, zeroed
     int ntm, ntn;
     int vec4;          // epilogue may use 16-B accesses (N, ld*, pointers all 4-element aligned)
+    int dbg;           // diagnostics only (gemm256 ablation: bit0 skip staging, bit1 skip MFMA phase)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -184,6 +185,10 @@ __device__ __forceinline__ void store_four(const GemmArgs& p, const RowMap& rm, 
 }
 
 bool gemm256_eligible(const skimi_gemm_desc* d);
+bool gemm_x3dma_eligible(const skimi_gemm_desc* d);
+int gemm_x3dma_launch(GemmArgs& a, const skimi_gemm_desc* d, hipStream_t st);
+size_t gemm_x3dma_scratch_bytes(const skimi_gemm_desc* d);
+int split_planes_launch(const float* x, long ld, long rows, int C, void* hi, void* lo, hipStream_t st);
 int gemm256_launch(GemmArgs& a, hipStream_t st);
 
 }  // namespace skimi

@@ -61,6 +61,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// 16-B-per-lane variant for the token streams (C a multiple of 256, one or two sources whose
+// halves are multiples of 256 too): lane l owns columns 256*i + 4*l .. +3, so every wave access
+// is a full 1-KiB row segment (4x fewer memory instructions than the scalar kernel).
+template <int NV>   // float4 chunks per lane = C / 256
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                            long ldx, long rows, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, void* out,
+                                                            int out_dtype, long ldo, long grp_rows, long grp_stride,
+                                                            long grp_off) {
+    constexpr int C = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const long orow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (orow >= rows) return;
+    const long row = grp_rows > 0 ? (orow / grp_rows) * grp_stride + grp_off + orow % grp_rows : orow;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 256 * i + 4 * lane;
+        const float* src = (x2 != nullptr && c >= C / 2) ? x2 + row * ldx + (c - C / 2) : x + row * ldx + c;
+        v[i] = *reinterpret_cast<const float4*>(src);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / (float)C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c2 = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c2 * c2 + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / (float)C) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 256 * i + 4 * lane;
+        float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
+        if (gamma) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            y[0] *= g.x; y[1] *= g.y; y[2] *= g.z; y[3] *= g.w;
+        }
+        if (beta) {
+            const float4 b = *reinterpret_cast<const float4*>(beta + c);
+            y[0] += b.x; y[1] += b.y; y[2] += b.z; y[3] += b.w;
+        }
+        if (out_dtype == SKIMI_F32) {
+            *reinterpret_cast<float4*>((float*)out + orow * ldo + c) = make_float4(y[0], y[1], y[2], y[3]);
+        } else {
+            bf16x4 h;
+            h[0] = (short)f2bf(y[0]); h[1] = (short)f2bf(y[1]); h[2] = (short)f2bf(y[2]); h[3] = (short)f2bf(y[3]);
+            *reinterpret_cast<bf16x4*>((unsigned short*)out + orow * ldo + c) = h;
+        }
+    }
+}
+
 int layernorm_launch(const float* x, const float* x2, int64_t ldx, int64_t rows, int C, const float* gamma,
                      const float* beta, float eps, void* out, int out_dtype, int64_t ldo, hipStream_t st,
                      int64_t grp_rows, int64_t grp_stride, int64_t grp_off) {
@@ -68,6 +121,28 @@ int layernorm_launch(const float* x, const float* x2, int64_t ldx, int64_t rows,
     SKIMI_CHECK_ARG(C <= 64 * 32, "skimi_layernorm: C=%d exceeds 2048", C);
     SKIMI_CHECK_ARG(x2 == nullptr || (C % 2 == 0), "skimi_layernorm: concat needs even C");
     dim3 grid((unsigned)cdiv(rows, 4)), block(256);
+    {
+        auto al16 = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
+        const bool vec = C % 256 == 0 && (x2 == nullptr || (C / 2) % 256 == 0) && ldx % 4 == 0 && ldo % 4 == 0 &&
+                         al16(x) && al16(x2) && al16(gamma) && al16(beta) &&
+                         ((uintptr_t)out & (out_dtype == SKIMI_F32 ? 15 : 7)) == 0;
+        if (vec) {
+#define LNV_GO(V) hipLaunchKernelGGL(layernorm_vec_kernel<V>, grid, block, 0, st, x, x2, (long)ldx, (long)rows, gamma, beta, eps, out, out_dtype, (long)ldo, (long)grp_rows, (long)grp_stride, (long)grp_off)
+            switch (C / 256) {
+                case 1: LNV_GO(1); break;
+                case 2: LNV_GO(2); break;
+                case 3: LNV_GO(3); break;
+                case 4: LNV_GO(4); break;
+                case 6: LNV_GO(6); break;
+                case 8: LNV_GO(8); break;
+                default: goto scalar_path;
+            }
+#undef LNV_GO
+            SKIMI_LAUNCH_CHECK();
+            return SKIMI_OK;
+        }
+    }
+scalar_path:
 #define LN_GO(V) hipLaunchKernelGGL(layernorm_kernel<V>, grid, block, 0, st, x, x2, (long)ldx, (long)rows, C, gamma, beta, eps, out, out_dtype, (long)ldo, (long)grp_rows, (long)grp_stride, (long)grp_off)
     const int nv = (int)cdiv(C, 64);
     if (nv <= 2) LN_GO(2);
@@ -132,11 +207,99 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(T* __restrict__ qkv, l
     else ((unsigned short*)p)[lane] = f2bf(t);
 }
 
+// Vectorised form: 8 lanes own one 64-wide head vector (8 contiguous features each, one 16-B
+// bf16 / two 16-B fp32 accesses), so a wave moves 8 head vectors per instruction instead of one.
+// LayerNorm reductions: in-lane over 8 values + 3 xor-shuffles inside the 8-lane group; the
+// RoPE partner of feature d (d +- 16 inside its 32-half) lives 2 lanes away.
+template <typename T>
+__global__ __launch_bounds__(256) void qknorm_rope_vec_kernel(T* __restrict__ qkv, long tokens, int heads,
+                                                              const float* __restrict__ qn_w,
+                                                              const float* __restrict__ qn_b,
+                                                              const float* __restrict__ kn_w,
+                                                              const float* __restrict__ kn_b, float eps,
+                                                              const int* __restrict__ pos,
+                                                              const float* __restrict__ rcos,
+                                                              const float* __restrict__ rsin, int npos) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long vec = gid >> 3;               // over tokens * 2 * heads
+    const int sub = (int)(gid & 7);          // features 8*sub .. 8*sub+7
+    const long total = tokens * 2 * heads;
+    const bool live = vec < total;
+    const long vv = live ? vec : total - 1;  // keep every lane in the shuffles
+    const long tok = vv / (2 * heads);
+    const int rem = (int)(vv - tok * 2 * heads);
+    const int which = rem / heads;
+    const int h = rem - which * heads;
+    T* p = qkv + ((tok * 3 + which) * heads + h) * 64 + 8 * sub;
+    float t[8];
+    if (sizeof(T) == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>((const float*)p + 4);
+        t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w; t[4] = b.x; t[5] = b.y; t[6] = b.z; t[7] = b.w;
+    } else {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = bf2f((unsigned short)a[j]);
+    }
+    const float* w = which ? kn_w : qn_w;
+    const float* b = which ? kn_b : qn_b;
+    if (w != nullptr) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += t[j];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        const float mean = s * (1.f / 64.f);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t[j] -= mean; q += t[j] * t[j]; }
+        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+        const float rstd = rsqrtf(q * (1.f / 64.f) + eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = t[j] * rstd * w[8 * sub + j] + (b ? b[8 * sub + j] : 0.f);
+    }
+    if (pos != nullptr) {
+        const int sect = sub >> 2;                    // features 0-31: y, 32-63: x
+        const int d0 = (8 * sub) & 31;                // first feature inside the 32-half
+        int pp = pos[tok * 2 + sect];
+        pp = min(max(pp, 0), npos - 1);
+        const float* ct = rcos + pp * 16 + (d0 & 15);
+        const float* st = rsin + pp * 16 + (d0 & 15);
+        const bool lower = d0 < 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float other = __shfl_xor(t[j], 2, 64);   // feature d +- 16
+            const float rot = lower ? -other : other;
+            t[j] = t[j] * ct[j] + rot * st[j];
+        }
+    }
+    if (!live) return;
+    if (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<float4*>((float*)p + 4) = make_float4(t[4], t[5], t[6], t[7]);
+    } else {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(t[j]);
+        *reinterpret_cast<bf16x8*>(p) = o;
+    }
+}
+
 int qknorm_rope_launch(void* qkv, int dtype, int64_t tokens, int heads, const float* qn_w, const float* qn_b,
                        const float* kn_w, const float* kn_b, float eps, const int32_t* pos,
                        const float* rope_cos, const float* rope_sin, int rope_npos, hipStream_t st) {
     SKIMI_CHECK_ARG(qkv && tokens > 0 && heads > 0, "skimi_qknorm_rope: bad arguments");
     SKIMI_CHECK_ARG(pos == nullptr || (rope_cos && rope_sin && rope_npos > 0), "skimi_qknorm_rope: pos without tables");
+    if (((uintptr_t)qkv & 15) == 0) {
+        const long threads = tokens * 2 * heads * 8;
+        dim3 g((unsigned)cdiv(threads, 256)), blk(256);
+        if (dtype == SKIMI_F32)
+            hipLaunchKernelGGL(qknorm_rope_vec_kernel<float>, g, blk, 0, st, (float*)qkv, (long)tokens, heads, qn_w, qn_b,
+                               kn_w, kn_b, eps, pos, rope_cos, rope_sin, rope_npos);
+        else
+            hipLaunchKernelGGL(qknorm_rope_vec_kernel<unsigned short>, g, blk, 0, st, (unsigned short*)qkv, (long)tokens,
+                               heads, qn_w, qn_b, kn_w, kn_b, eps, pos, rope_cos, rope_sin, rope_npos);
+        SKIMI_LAUNCH_CHECK();
+        return SKIMI_OK;
+    }
     const long total = tokens * 2 * heads;
     dim3 grid((unsigned)cdiv(total, 4)), block(256);
     if (dtype == SKIMI_F32)

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "kernels.h"
 #include "track_kernels.h"
 #include "vggt_kernels.h"
@@ -34,6 +35,7 @@ struct Lin {              // out = A . W^T (+ b)
     float* b = nullptr;
     int N = 0, K = 0;     // K as seen by the GEMM (padded)
     int prec = SKIMI_PREC_BF16X3;
+    void* w_split = nullptr;   // BF16X3 only: bf16 [hi | lo] planes for the LDS-DMA kernel (wide 3x3 convs)
 };
 struct LNw { float* g = nullptr; float* b = nullptr; };
 struct BlockW {
@@ -212,6 +214,16 @@ struct Packer {
             perm = tmp;
         }
         c.lin = pack_matrix(perm, Co, Ci * k * k, prec);
+        // wide fp32-accurate 3x3 convs also get bf16 hi|lo planes: the LDS-DMA bf16x3 kernel
+        // (gemm_x3dma.hip) beats the generic one there (measured: +28 % at 256 -> 256 channels;
+        // no gain at N = 128 or for 1x1, which keep the generic kernel)
+        if (!rc && prec == SKIMI_PREC_BF16X3 && k == 3 && Co >= 256 && Ci % 32 == 0) {
+            const size_t n = (size_t)Co * c.lin.K;
+            c.lin.w_split = dmalloc(n * 4);
+            if (c.lin.w_split)
+                rc = split_planes_launch((const float*)c.lin.w, c.lin.K, Co, c.lin.K, c.lin.w_split,
+                                         (unsigned short*)c.lin.w_split + n, st);
+        }
         if (tmp) { (void)hipStreamSynchronize(st); (void)hipFree(tmp); }
         if (bias) c.lin.b = keep(p + ".bias", Co);
         return c;
@@ -303,8 +315,16 @@ struct Ctx {
     static size_t esz(int dt) { return dt == SKIMI_F32 ? 4 : 2; }
 
     void gemm(skimi_gemm_desc& d) {
-        if (rc || dry()) return;
-        rc = gemm_dispatch(&d, st, slab, slab_bytes, 0);
+        // wide fp32-accurate 3x3 convs: lend arena scratch for the activation planes of the
+        // LDS-DMA bf16x3 kernel (released right after the launch is enqueued: stream order keeps
+        // later users of that memory behind it)
+        const size_t mk = ar.mark();
+        if (d.W_split != nullptr) {
+            d.x3_scratch_bytes = gemm_x3dma_scratch_bytes(&d);
+            d.x3_scratch = ar.alloc(d.x3_scratch_bytes);
+        }
+        if (!rc && !dry()) rc = gemm_dispatch(&d, st, slab, slab_bytes, 0);
+        ar.release(mk);
     }
     skimi_gemm_desc desc(const Lin& L, const void* A, int a_dt, long lda, int M, void* out, int out_dt, long ldo) {
         skimi_gemm_desc d;
@@ -313,6 +333,7 @@ struct Ctx {
         d.A = A; d.a_dtype = a_dt; d.lda = lda;
         d.W = L.w; d.w_dtype = L.wdt; d.ldw = L.K;
         d.prec = L.prec;
+        d.W_split = M >= 4096 ? L.w_split : nullptr;
         d.bias = L.b;
         d.out = out; d.out_dtype = out_dt; d.ldo = ldo;
         return d;

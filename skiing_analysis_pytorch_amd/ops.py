@@ -27,7 +27,7 @@ def _require_cuda(*ts):
 
 def gemm(a, w, *, prec=PREC_BF16X3, bias=None, gamma=None, resid=None, act=ACT_NONE, out=None,
          out_dtype=torch.float32, conv=None, resid_map=None, pixel_shuffle=None, splitk_scratch=None,
-         force_splitk=0, M=None, lda=None):
+         force_splitk=0, M=None, lda=None, w_split=None, x3_scratch=None):
     """out = epilogue(gather(a) @ w.T).  a: [rows, lda] (f32|bf16), w: [N, K].
 
     conv = dict(N,H,W,C,KH,KW,stride,pad,dil,OH,OW) selects the implicit-im2col gather;
@@ -71,6 +71,10 @@ def gemm(a, w, *, prec=PREC_BF16X3, bias=None, gamma=None, resid=None, act=ACT_N
         d.splitk_scratch = ptr(splitk_scratch)
         d.splitk_scratch_bytes = splitk_scratch.numel() * splitk_scratch.element_size()
     d.force_splitk = force_splitk
+    if w_split is not None:
+        d.W_split = ptr(w_split)
+        d.x3_scratch = ptr(x3_scratch)
+        d.x3_scratch_bytes = x3_scratch.numel() * x3_scratch.element_size()
     check(lib().skimi_gemm(C.byref(d), _lib.current_stream()), "skimi_gemm")
     return out
 
@@ -103,4 +107,14 @@ def attention(qkv, batch, seq, heads, head_dim):
     out = torch.empty((batch * seq, heads * head_dim), dtype=qkv.dtype, device=qkv.device)
     check(lib().skimi_attention(ptr(qkv), ptr(out), _dt(qkv), batch, seq, heads, head_dim, _lib.current_stream()),
           "skimi_attention")
+    return out
+
+
+def split_planes(x):
+    """fp32 [rows, C] -> bf16 [2, rows, C] (hi, lo) with hi + lo ~= x to ~2^-17 relative."""
+    _require_cuda(x)
+    rows, Cc = x.shape
+    out = torch.empty((2, rows, Cc), dtype=torch.bfloat16, device=x.device)
+    check(lib().skimi_split_planes(ptr(x), x.stride(0), rows, Cc, ptr(out[0]), ptr(out[1]), _lib.current_stream()),
+          "skimi_split_planes")
     return out

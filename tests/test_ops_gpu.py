@@ -223,3 +223,57 @@ def test_gemm256_lds_dma_path(M, N, K):
     ai = ((torch.arange(M * K, device=DEV).reshape(M, K) * 7 + 3) % 9 - 4).to(torch.bfloat16)
     wi = ((torch.arange(N * K, device=DEV).reshape(N, K) * 5 + 1) % 7 - 3).to(torch.bfloat16)
     assert torch.equal(ops.gemm(ai, wi, prec=PREC_BF16), ai.float() @ wi.float().T)
+
+
+def _x3(a, w, **kw):
+    """bf16x3 fast path: weights also as pre-split planes + scratch for the activation planes."""
+    rows = a.shape[0]
+    scratch = torch.empty(rows * a.shape[1], dtype=torch.float32, device=DEV)
+    return ops.gemm(a, w, prec=PREC_BF16X3, w_split=ops.split_planes(w), x3_scratch=scratch, **kw)
+
+
+def test_split_planes_reconstructs():
+    x = _rand(1000, 256, seed=80) * 7
+    p = ops.split_planes(x)
+    rec = p[0].float() + p[1].float()
+    assert ((rec - x).abs() / x.abs().clamp_min(1e-20)).max().item() < 2 ** -15
+    assert torch.equal(p[0], x.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 256), (5000, 128, 1024), (10952, 256, 2048), (4100, 512, 392)])
+def test_gemm_x3dma_plain(M, N, K):
+    a, w, b, r = _rand(M, K, seed=81), _rand(N, K, seed=82, scale=1 / math.sqrt(K)), _rand(N, seed=83), _rand(M, N, seed=84)
+    ref = a @ w.T + b
+    assert _rel(_x3(a, w, bias=b), ref) < 2e-5
+    assert _rel(_x3(a, w, bias=b, act=ACT_RELU, resid=r), F.relu(ref) + r) < 2e-5
+    ai = torch.arange(M * K, device=DEV, dtype=torch.float32).reshape(M, K) % 13 - 6
+    wi = (torch.arange(N * K, device=DEV, dtype=torch.float32).reshape(N, K) * 3 % 11) - 5
+    assert torch.equal(_x3(ai, wi), ai @ wi.T)
+
+
+@pytest.mark.parametrize("cfg", [dict(H=74, W=74, C=64, Co=256, k=3, s=1, p=1), dict(H=75, W=73, C=128, Co=128, k=3, s=2, p=1),
+                                 dict(H=70, W=70, C=32, Co=256, k=3, s=1, p=1)])
+def test_gemm_x3dma_conv(cfg):
+    H, W_, Cc, Co, k, s, p = (cfg[x] for x in ("H", "W", "C", "Co", "k", "s", "p"))
+    n = 2
+    x = _rand(n, H, W_, Cc, seed=85)
+    w = _rand(Co, Cc, k, k, seed=86, scale=1 / math.sqrt(Cc * k * k))
+    b = _rand(Co, seed=87)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=s, padding=p)
+    OH, OW = ref.shape[2], ref.shape[3]
+    wp = w.permute(0, 2, 3, 1).reshape(Co, k * k * Cc).contiguous()
+    conv = dict(N=n, H=H, W=W_, C=Cc, KH=k, KW=k, stride=s, pad=p, dil=1, OH=OH, OW=OW)
+    out = _x3(x.reshape(-1, Cc), wp, bias=b, conv=conv)
+    assert out.shape[0] >= 2048
+    assert _rel(out, ref.permute(0, 2, 3, 1).reshape(-1, Co)) < 2e-5
+
+
+def test_gemm_x3dma_pixel_shuffle():
+    n, H, W_, Cc, Co, s = 3, 37, 37, 256, 256, 2
+    x = _rand(n, H, W_, Cc, seed=88)
+    w = _rand(Cc, Co, s, s, seed=89, scale=0.1)
+    b = _rand(Co, seed=90)
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2), w, b, stride=s).permute(0, 2, 3, 1)
+    wp = w.permute(2, 3, 1, 0).reshape(s * s * Co, Cc).contiguous()
+    out = _x3(x.reshape(-1, Cc), wp, bias=b.repeat(s * s), pixel_shuffle=(s, Co, n, H, W_))
+    assert _rel(out, ref) < 2e-5
