@@ -18,6 +18,8 @@ namespace skimi {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& p, int s) {
     bf16x8 r;
@@ -26,7 +28,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& p, int s) {
     return r;
 }
 
-__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a, int nqb) {
+__global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const AttnArgs a, int nqb) {
     constexpr int KV = 64;                 // keys per tile
     constexpr int TILE = KV * 64 * 2;      // bytes of one K (or V) tile
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [buf][K|V]
@@ -62,39 +64,28 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a, int
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
 
-    // staging coordinates: 2 x 16-B chunks of K and of V per thread
-    int st_r[2], st_c[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = i * 256 + tid;
-        st_r[i] = c >> 3;
-        st_c[i] = c & 7;
-    }
-    bf16x8 kreg[2], vreg[2];
-    auto issue = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            // unconditional loads from a clamped row (a predicated load would serialise the burst);
-            // rows past the end are zeroed in registers in write()
-            const int key = min(kt * KV + st_r[i], a.seq_k - 1);
-            kreg[i] = *reinterpret_cast<const bf16x8*>(K + (long)key * a.k_row + st_c[i] * 8);
-            vreg[i] = *reinterpret_cast<const bf16x8*>(V + (long)key * a.v_row + st_c[i] * 8);
-        }
-    };
-    // K rows: chunk ^= (row>>1)&7  (conflict-free ds_read_b128 of 32 rows at one chunk)
-    // V rows: chunk ^= ((row>>1)&1)<<2 (conflict-free ds_read_b64_tr_b16 of 4-row blocks)
-    auto write = [&](int buf, int kt) {
+    // K/V staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction lands 8 rows x 128 B
+    // linearly in LDS, so both bank swizzles are applied to the per-lane SOURCE chunk:
+    //   K rows: chunk ^= (row>>1)&7          (conflict-free ds_read_b128 of 32 rows at one chunk)
+    //   V rows: chunk ^= ((row>>1)&1)<<2     (conflict-free ds_read_b64_tr_b16 of 4-row blocks)
+    // Rows past the end are clamped to the last valid row (finite data; their scores are masked
+    // to -inf, so their P is exactly 0).  No staging registers, no ds_write pass.
+    const int nkt = (a.seq_k + KV - 1) / KV;
+    const bool ragged = (a.seq_k & (KV - 1)) != 0;
+    const int srow = lane >> 3, sch = lane & 7;
+    auto issue = [&](int buf, int kt) {
         char* kb = smem + buf * 2 * TILE;
         char* vb = kb + TILE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = st_r[i], c = st_c[i];
-            if (kt * KV + r >= a.seq_k) {   // V rows past the end must be finite zeros (0 * NaN)
-                kreg[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                vreg[i] = kreg[i];
-            }
-            *reinterpret_cast<bf16x8*>(kb + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kreg[i];
-            *reinterpret_cast<bf16x8*>(vb + r * 128 + ((c ^ (((r >> 1) & 1) << 2)) << 4)) = vreg[i];
+        for (int j = 0; j < 2; ++j) {
+            const int row = 8 * (2 * wave + j) + srow;                 // tile row 0..63
+            const int key = min(kt * KV + row, a.seq_k - 1);
+            const int kc = sch ^ ((row >> 1) & 7);
+            const int vc = sch ^ (((row >> 1) & 1) << 2);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(K + (long)key * a.k_row + kc * 8),
+                                             (lds_void*)(kb + (2 * wave + j) * 8 * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(V + (long)key * a.v_row + vc * 8),
+                                             (lds_void*)(vb + (2 * wave + j) * 8 * 128), 16, 0, 0);
         }
     };
 
@@ -103,36 +94,39 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a, int
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m = -INFINITY, lsum = 0.f;
+    // row sums l[q] ride on the matrix pipe: lacc = ones^T . P^T accumulates sum_key P[key][q] into
+    // every register of a 32x32 tile (the loop is VALU-bound: 4 extra MFMAs replace 32 v_add),
+    // and it sums exactly the bf16-rounded P that the PV product uses
+    f32x16 lacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    float m = -INFINITY;
     const float c2 = a.scale * 1.44269504088896340736f;   // softmax scale folded into exp2
 
-    const int nkt = (a.seq_k + KV - 1) / KV;
-    issue(0);
-    write(0, 0);
-    __syncthreads();
+    issue(0, 0);
+    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) ahead of the barrier
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) issue(kt + 1);
+        if (kt + 1 < nkt) issue(cur ^ 1, kt + 1);
         const char* kb = smem + cur * 2 * TILE;
         const char* vb = kb + TILE;
 
         // ---- S^T = K Q^T : two 32-key sub-tiles ----
         f32x16 s[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
             const int row = t * 32 + l31;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf =
                     *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+                // the first k-step takes the constant 0 as C (inline operand: no 16-register clear)
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : s[t], 0, 0, 0);
             }
         }
         // mask keys past the end (last tile only)
-        if (kt == nkt - 1 && (a.seq_k & (KV - 1)) != 0) {
+        if (ragged && kt == nkt - 1) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -149,22 +143,25 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a, int
             for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[t][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float mnew = fmaxf(m, mloc);
-        const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c2);
-        const float mb = mnew * c2;
-        m = mnew;
-        float psum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
+        const float nmb = -(mnew * c2);
+        // exact skip of the O / l rescale when no lane's running max moved (alpha == 1 for the
+        // whole wave): after the first few tiles this is the common case
+        if (!__all(mnew == m)) {
+            const float alpha = __builtin_amdgcn_exp2f((m - mnew) * c2);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[t][r] = __builtin_amdgcn_exp2f(s[t][r] * c2 - mb);
-                psum += s[t][r];
+                o[0][r] *= alpha;
+                o[1][r] *= alpha;
+                lacc[r] *= alpha;
             }
-        lsum = lsum * alpha + psum;
+            m = mnew;
+        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) {
+            // one v_fma per score (the build runs with -ffp-contract=off, so spell the fma out)
+            s[0][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][r], c2, nmb));
+            s[1][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][r], c2, nmb));
+        }
 
         // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -172,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a, int
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 pf = pack8(s[t], ks);
+                lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     // tr-read block: rows key0 + q (q = (lane&15)>>2), cols dcol0 + 4p (p = lane&3)
@@ -194,12 +192,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const AttnArgs a, int
             }
         }
 
-        if (kt + 1 < nkt) write(cur ^ 1, kt + 1);
         __syncthreads();
     }
 
-    lsum += __shfl_xor(lsum, 32, 64);
-    const float inv = 1.f / lsum;
+    const float inv = 1.f / lacc[0];   // every register of lacc holds this lane's (query's) row sum
     const int q = q0 + l31;
     if (q < a.seq_q) {
         unsigned short* op = O + (long)q * a.o_row;
