@@ -427,8 +427,10 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     const long t128 = cdiv(d->M, 128) * cdiv(d->N, 128);
     const bool small = t128 < 128;
     const int BM = small ? 64 : 128;
+    // narrow outputs (e.g. the DPT 128 -> 32 conv): a 128 x 64 tile halves the wasted N columns
+    const int BN = (BM == 128 && d->N <= 64) ? 64 : BM;
     a.ntm = (int)cdiv(d->M, BM);
-    a.ntn = (int)cdiv(d->N, BM);
+    a.ntn = (int)cdiv(d->N, BN);
     const long tiles = (long)a.ntm * a.ntn;
     int splitk = 1;
     const int nkt = (int)cdiv(d->K, BK);
@@ -458,7 +460,18 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     if (prof) prof_before(st);
     const bool af = d->a_dtype == SKIMI_F32, wf = d->w_dtype == SKIMI_F32;
 #define SKIMI_GO(BM_, BK_, NS_, TA_, TW_) rc = launch_cfg<BM_, BM_, BK_, NS_, TA_, TW_>(a, st)
-    if (d->prec == SKIMI_PREC_BF16) {
+    if (BN == 64 && BM == 128) {
+        if (d->prec == SKIMI_PREC_BF16) {
+            if (af && wf) rc = launch_cfg<128, 64, 64, 1, float, float>(a, st);
+            else if (af) rc = launch_cfg<128, 64, 64, 1, float, unsigned short>(a, st);
+            else if (wf) rc = launch_cfg<128, 64, 64, 1, unsigned short, float>(a, st);
+            else rc = launch_cfg<128, 64, 64, 1, unsigned short, unsigned short>(a, st);
+        } else {
+            SKIMI_CHECK_ARG(wf, "skimi_gemm: BF16X3 needs fp32 weights");
+            if (af) rc = launch_cfg<128, 64, 32, 3, float, float>(a, st);
+            else rc = launch_cfg<128, 64, 32, 3, unsigned short, float>(a, st);
+        }
+    } else if (d->prec == SKIMI_PREC_BF16) {
         if (BM == 128) {
             if (af && wf) SKIMI_GO(128, 64, 1, float, float);
             else if (af) SKIMI_GO(128, 64, 1, float, unsigned short);

@@ -277,3 +277,19 @@ def test_gemm_x3dma_pixel_shuffle():
     wp = w.permute(2, 3, 1, 0).reshape(s * s * Co, Cc).contiguous()
     out = _x3(x.reshape(-1, Cc), wp, bias=b.repeat(s * s), pixel_shuffle=(s, Co, n, H, W_))
     assert _rel(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("prec", [PREC_BF16X3, PREC_BF16])
+def test_gemm_narrow_n_tile(prec):
+    """N <= 64 with many rows takes the 128 x 64 tile (the DPT 128 -> 32 output conv)."""
+    n, H, W_, Cc, Co = 2, 120, 130, 128, 32
+    x = _rand(n, H, W_, Cc, seed=95)
+    w = _rand(Co, Cc, 3, 3, seed=96, scale=1 / math.sqrt(Cc * 9))
+    b = _rand(Co, seed=97)
+    ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)).permute(0, 2, 3, 1).reshape(-1, Co)
+    wp = w.permute(0, 2, 3, 1).reshape(Co, 9 * Cc).contiguous()
+    if prec == PREC_BF16:
+        wp = wp.to(torch.bfloat16)
+    conv = dict(N=n, H=H, W=W_, C=Cc, KH=3, KW=3, stride=1, pad=1, dil=1, OH=H, OW=W_)
+    out = ops.gemm(x.reshape(-1, Cc), wp, prec=prec, bias=b, act=ACT_RELU, conv=conv)
+    assert _rel(out, ref) < (2e-5 if prec == PREC_BF16X3 else 1e-2)
