@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1, help="time steps per call (B)")
+    ap.add_argument("--batch", type=int, default=4, help="time steps of the clip per call (B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=2, help="views of the bounded CPU-baseline sample")
     args = ap.parse_args()
@@ -52,10 +52,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    use_dist = "WORLD_SIZE" in os.environ and "RANK" in os.environ   # launched by torch.distributed.run
+    torch.cuda.set_device(local_rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from skiing_analysis_pytorch_amd import _lib, vggt, weights as W
@@ -82,7 +83,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     lib = _lib.lib()
     # roofline leg: bracket every global-attention launch (seq = S*1374) of the timed region
@@ -93,13 +94,13 @@ def main():
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t1 = time.perf_counter()
     ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
     _lib.check(lib.skimi_profile_stop(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "profile_stop")
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -136,14 +137,14 @@ def main():
                             "avg_launch_us": avg_s * 1e6, "launches": int(n.value),
                             "flops_per_launch": flops_per_launch}
     if rank == 0 and cpu_sd is not None:
-        line["cpu_baseline"] = cpu_baseline(cpu_sd, cfg, args.cpu_views)
+        line["cpu_baseline"], line["parity_vs_cpu_oracle"] = cpu_baseline(cpu_sd, cfg, args.cpu_views, model, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
-def cpu_baseline(cpu_sd, cfg, views):
+def cpu_baseline(cpu_sd, cfg, views, model, dev):
     """The oracle (fp32 CPU restatement of the reference, oracle/vggt_oracle.py) on a bounded
     sample: ONE `views`-view 518x518 step on this host's cores.  An 8-view step costs
     flops(8)/flops(views) more; the value is scaled by that ratio and the sample says so."""
@@ -162,12 +163,21 @@ def cpu_baseline(cpu_sd, cfg, views):
     d["enable_track"] = False
     with torch.no_grad():
         t0 = time.perf_counter()
-        vggt_oracle.vggt_forward(cpu_sd, img, d)
+        ref = vggt_oracle.vggt_forward(cpu_sd, img, d)
         dt = time.perf_counter() - t0
     ratio = vggt_flops_per_step(S_VIEWS) / vggt_flops_per_step(views)
-    return {"value": 1.0 / (dt * ratio), "unit": "frames/s", "cores": threads, "kind": "port",
+    base = {"value": 1.0 / (dt * ratio), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"one {views}-view 518x518 step = {dt:.1f} s measured; 8-view step = x{ratio:.2f} FLOPs (extrapolated)",
             "measured_seconds": dt}
+    # the same full-size input through the benchmarked HIP model (bf16 aggregator, fp32-accurate
+    # heads) against the fp32 CPU oracle: the checker, outside the timed region
+    got = model(img.to(dev), want={"camera", "depth"})
+    pe = (got["pose_enc"].cpu() - ref["pose_enc"]).abs().max().item()
+    rel = ((got["depth"].cpu() - ref["depth"]).abs() / (ref["depth"].abs() + 1.0))
+    parity = {"sample": f"VGGT-1B, {views} views x 518x518, synthetic weights; bf16 aggregator vs fp32 CPU oracle",
+              "pose_enc_max_abs_err": pe, "depth_rel_err_median": rel.median().item(),
+              "depth_rel_err_p99": rel.flatten().kthvalue(int(0.99 * rel.numel())).values.item()}
+    return base, parity
 
 
 if __name__ == "__main__":
