@@ -228,6 +228,12 @@ int skimi_vggt_set_weight(skimi_vggt*, const char* key, const float* data, int64
 /* check every key of the configured model is present with the right size, repack
  * (conv taps, bf16 copies, padded K) and release the staged fp32 copies */
 int skimi_vggt_finalize(skimi_vggt*);
+/* DINOv2 positional embedding for an input size other than the one the model was built for:
+ * pos_embed = [1 + (H/patch)*(W/patch), embed_dim] fp32 — row 0 the class position, the rest the
+ * 37x37 grid resized with bicubic + antialias exactly as interpolate_pos_encoding does
+ * (vggt/vggt/layers/vision_transformer.py:180-212).  A per-resolution constant, computed once by
+ * the host side (skiing_analysis_pytorch_amd/vggt.py); without it such sizes are rejected. */
+int skimi_vggt_set_pos_embed(skimi_vggt*, int32_t H, int32_t W, const float* pos_embed, int32_t on_device);
 size_t skimi_vggt_workspace_bytes(skimi_vggt*, int32_t B, int32_t S, int32_t H, int32_t W, int32_t n_query);
 
 /* device output buffers (fp32); a NULL pointer skips the store (a head whose outputs are all

@@ -95,6 +95,22 @@ def block(sd, prefix, x, num_heads, pos=None, qk_norm=False, eps=1e-5):
 # ---------------------------------------------------------------------------------------
 # Aggregator  (vggt/vggt/models/aggregator.py, layers/vision_transformer.py, layers/patch_embed.py)
 # ---------------------------------------------------------------------------------------
+def interpolate_pos_encoding(pos_embed, npatch, H, W, patch):
+    """vision_transformer.py:180-212 with interpolate_antialias=True, interpolate_offset=0.0
+    (aggregator.py:147-148): identity for the native square size, otherwise bicubic + antialias
+    resize of the M x M grid to (H/patch, W/patch); the class position is kept."""
+    N = pos_embed.shape[1] - 1
+    if npatch == N and H == W:
+        return pos_embed
+    pe = pos_embed.float()
+    dim = pe.shape[-1]
+    M = int(math.sqrt(N))
+    assert N == M * M
+    grid = F.interpolate(pe[:, 1:].reshape(1, M, M, dim).permute(0, 3, 1, 2), mode="bicubic", antialias=True,
+                         size=(H // patch, W // patch))
+    return torch.cat((pe[:, 0].unsqueeze(0), grid.permute(0, 2, 3, 1).view(1, -1, dim)), dim=1)
+
+
 def dino_patch_tokens(sd, prefix, x, cfg):
     """vision_transformer.py:214-226 (prepare tokens), :252-268 (blocks, final norm, drop cls+reg).
     Square input of the configured size only (interpolate_pos_encoding short-circuit :184-185)."""
@@ -102,9 +118,7 @@ def dino_patch_tokens(sd, prefix, x, cfg):
     t = F.conv2d(x, sd[prefix + ".patch_embed.proj.weight"], sd[prefix + ".patch_embed.proj.bias"], stride=p)
     t = t.flatten(2).transpose(1, 2)                                       # patch_embed.py:73-74
     t = torch.cat((sd[prefix + ".cls_token"].expand(t.shape[0], -1, -1), t), dim=1)
-    pe = sd[prefix + ".pos_embed"]
-    assert pe.shape[1] == t.shape[1] and x.shape[-1] == x.shape[-2], "non-square / resized pos_embed not restated"
-    t = t + pe
+    t = t + interpolate_pos_encoding(sd[prefix + ".pos_embed"], t.shape[1] - 1, x.shape[-2], x.shape[-1], p)
     reg = sd[prefix + ".register_tokens"]
     t = torch.cat((t[:, :1], reg.expand(t.shape[0], -1, -1), t[:, 1:]), dim=1)
     for i in range(cfg["dino_depth"]):

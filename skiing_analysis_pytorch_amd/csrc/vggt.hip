@@ -99,6 +99,7 @@ struct skimi_vggt {
     Lin patch_proj;                 // [C, Kp] patchify GEMM (K = 3*p*p padded to 8)
     int patch_kp = 0;
     float* dino_pos = nullptr;      // pos_embed [1 + np0, C]
+    std::map<std::pair<int, int>, float*> dino_pos_alt;   // (H, W) -> resized pos_embed [1 + ph*pw, C]
     float* dino_special = nullptr;  // [2][1+R][C] (cls + pos[0], registers), both selector rows equal
     float* agg_special = nullptr;   // [2][1+R][C] camera/register tokens for frame 0 / others
     std::vector<BlockW> dino, frame, global;
@@ -720,7 +721,8 @@ int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query,
             d.out_rows_per_batch = np; d.out_batch_stride = P; d.out_row_off = nsp;
             if (cfg.use_dino) {
                 // + pos_embed[1 + p] (vision_transformer.py:221), broadcast over frames
-                d.resid = h->dino_pos; d.ldr = C;
+                const bool native = H == W && H == cfg.dino_img_size;
+                d.resid = native ? h->dino_pos : h->dino_pos_alt.at({H, W}); d.ldr = C;
                 d.resid_rows_per_batch = np; d.resid_batch_stride = 0; d.resid_row_off = 1;
             }
             c.gemm(d);
@@ -813,6 +815,7 @@ void skimi_vggt_destroy(skimi_vggt* h) {
     for (auto& kv : h->raw) (void)hipFree(kv.second.first);
     for (void* p : h->owned) (void)hipFree(p);
     for (void* p : h->prep_owned) (void)hipFree(p);
+    for (auto& kv : h->dino_pos_alt) (void)hipFree(kv.second);
     delete h;
 }
 
@@ -830,6 +833,25 @@ int skimi_vggt_set_weight(skimi_vggt* h, const char* key, const float* data, int
     if (it != h->raw.end()) (void)hipFree(it->second.first);
     h->raw[key] = {d, n};
     h->finalized = false;
+    return SKIMI_OK;
+}
+
+int skimi_vggt_set_pos_embed(skimi_vggt* h, int32_t H, int32_t W, const float* pos_embed, int32_t on_device) {
+    SKIMI_CHECK_ARG(h && pos_embed && h->cfg.use_dino, "skimi_vggt_set_pos_embed: needs a DINOv2 model and a table");
+    const int p = h->cfg.patch_size;
+    SKIMI_CHECK_ARG(H > 0 && W > 0 && H % p == 0 && W % p == 0, "skimi_vggt_set_pos_embed: bad size %dx%d", H, W);
+    const size_t n = ((size_t)(H / p) * (W / p) + 1) * h->cfg.embed_dim;
+    float* d = nullptr;
+    SKIMI_HIP(hipMalloc((void**)&d, n * 4));
+    hipError_t e = hipMemcpy(d, pos_embed, n * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        set_error("skimi_vggt_set_pos_embed: copy failed: %s", hipGetErrorString(e));
+        return SKIMI_ERR_HIP;
+    }
+    auto it = h->dino_pos_alt.find({H, W});
+    if (it != h->dino_pos_alt.end()) (void)hipFree(it->second);
+    h->dino_pos_alt[{H, W}] = d;
     return SKIMI_OK;
 }
 
@@ -927,9 +949,10 @@ static int check_shape(const skimi_vggt* h, int B, int S, int H, int W) {
     // patch_embed.py:69-70
     SKIMI_CHECK_ARG(H > 0 && H % p == 0, "Input image height %d is not a multiple of patch height %d", H, p);
     SKIMI_CHECK_ARG(W > 0 && W % p == 0, "Input image width %d is not a multiple of patch width: %d", W, p);
-    if (h->cfg.use_dino)
-        SKIMI_CHECK_ARG(H == W && H == h->cfg.dino_img_size,
-                        "DINOv2 pos_embed interpolation for %dx%d (model built for %d) is not built yet", H, W,
+    if (h->cfg.use_dino && !(H == W && H == h->cfg.dino_img_size))
+        SKIMI_CHECK_ARG(h->dino_pos_alt.count({H, W}) != 0,
+                        "DINOv2 pos_embed for %dx%d (model built for %d) has not been registered: call "
+                        "skimi_vggt_set_pos_embed with the bicubic-antialias resized table first", H, W,
                         h->cfg.dino_img_size);
     return SKIMI_OK;
 }

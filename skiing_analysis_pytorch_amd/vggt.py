@@ -114,7 +114,30 @@ class VGGT:
             check(lib().skimi_vggt_set_weight(self._h, k.encode(), t.data_ptr(), t.numel(), int(t.is_cuda)),
                   f"set_weight({k})")
         check(lib().skimi_vggt_finalize(self._h), "skimi_vggt_finalize")
+        if self.cfg.use_dino:   # kept on the host for interpolate_pos_encoding at other input sizes
+            self._pos_embed = state_dict["aggregator.patch_embed.pos_embed"].detach().to("cpu", torch.float32)
+            self._pos_sizes = set()
         return self
+
+    def _ensure_pos_embed(self, H: int, W: int):
+        """vision_transformer.py:180-212 (interpolate_pos_encoding, antialias=True, offset 0):
+        a per-resolution constant table, computed once on the host and registered with the
+        library.  (The reference names the height `w` and the width `h`; size=(w0, h0) is
+        (rows, cols).)"""
+        cfg = self.cfg
+        if not cfg.use_dino or (H == W == cfg.img_size) or (H, W) in self._pos_sizes:
+            return
+        pe = self._pos_embed
+        N = pe.shape[1] - 1
+        M = int(N ** 0.5)
+        assert N == M * M
+        dim = pe.shape[-1]
+        w0, h0 = H // cfg.patch_size, W // cfg.patch_size
+        grid = torch.nn.functional.interpolate(pe[:, 1:].reshape(1, M, M, dim).permute(0, 3, 1, 2), mode="bicubic",
+                                               antialias=True, size=(w0, h0))
+        table = torch.cat((pe[:, 0], grid.permute(0, 2, 3, 1).reshape(-1, dim)), dim=0).contiguous()
+        check(lib().skimi_vggt_set_pos_embed(self._h, H, W, table.data_ptr(), 0), "skimi_vggt_set_pos_embed")
+        self._pos_sizes.add((H, W))
 
     def __call__(self, images, query_points=None, **kw):
         return self.forward(images, query_points, **kw)
@@ -164,6 +187,7 @@ class VGGT:
             P = 1 + cfg.num_register_tokens + (H // cfg.patch_size) * (W // cfg.patch_size)
             preds["tokens_last"] = torch.empty((B, S, P, 2 * cfg.embed_dim), **f32)
             outs.tokens_last = ptr(preds["tokens_last"])
+        self._ensure_pos_embed(H, W)
         need = lib().skimi_vggt_workspace_bytes(self._h, B, S, H, W, nq)
         if need == 0:
             raise _lib.SkimiError(lib().skimi_last_error().decode())

@@ -25,7 +25,7 @@ def _maxerr(a, b):
     return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
 
 
-@pytest.mark.parametrize("name", ["tiny_conv", "tiny_dino"])
+@pytest.mark.parametrize("name", ["tiny_conv", "tiny_dino", "tiny_dino_rect"])
 def test_vggt_fp32_mode_matches_reference(golden_dir, name):
     """PREC_BF16X3 everywhere: the mode that must meet the 1e-3 bar against the fp32 CPU reference."""
     g, cfg, sd, images = _load(golden_dir, name)

@@ -84,6 +84,10 @@ TINY_CONFIGS = {
         track_hidden=128, track_corr_levels=3, track_corr_radius=3, track_iters=3, track_depth=2,
         track_heads=8, track_virtual=16)),
     # DINOv2 ViT-S/14-reg patch embed (12 blocks, LayerNorm eps 1e-6, LayerScale), no track head
+    "tiny_dino_rect": dict(S=2, H=42, W=70, queries=0, cfg=dict(   # non-square: resized pos_embed
+        img_size=70, embed_dim=384, depth=2, num_heads=6, patch_embed="dinov2_vits14_reg", dino_depth=12,
+        dino_heads=6, cam_trunk_depth=1, cam_heads=6, dpt_features=64, dpt_out_channels=(64, 64, 128, 128),
+        dpt_layers=(0, 0, 1, 1), enable_track=False)),
     "tiny_dino": dict(S=2, H=70, W=70, queries=0, cfg=dict(
         img_size=70, embed_dim=384, depth=2, num_heads=6, patch_embed="dinov2_vits14_reg", dino_depth=12,
         dino_heads=6, cam_trunk_depth=1, cam_heads=6, dpt_features=64, dpt_out_channels=(64, 64, 128, 128),
