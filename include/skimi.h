@@ -126,6 +126,9 @@ typedef struct skimi_gemm_desc {
     void* splitk_scratch;
     uint64_t splitk_scratch_bytes;
     int32_t force_splitk;
+    /* 1 = the caller guarantees the scratch is all zero on entry (every split-K launch leaves it
+     * zeroed again), so no memset is issued; 0 = the launch zeroes what it needs first */
+    int32_t splitk_scratch_zeroed;
     /* optional fast path of SKIMI_PREC_BF16X3 for large shapes: W_split = the same weights as two
      * bf16 planes [hi | lo], each [N, ldw] (skimi_split_planes), and x3_scratch = caller-owned
      * scratch of >= 4 bytes per element of the A buffer the launch touches, where A is split once

@@ -48,7 +48,7 @@ class GemmDesc(C.Structure):
         ("store_mode", C.c_int32), ("ps_s", C.c_int32), ("ps_C", C.c_int32),
         ("splitk_scratch", C.c_void_p),
         ("splitk_scratch_bytes", C.c_uint64),
-        ("force_splitk", C.c_int32),
+        ("force_splitk", C.c_int32), ("splitk_scratch_zeroed", C.c_int32),
         ("W_split", C.c_void_p), ("x3_scratch", C.c_void_p), ("x3_scratch_bytes", C.c_uint64),
     ]
 

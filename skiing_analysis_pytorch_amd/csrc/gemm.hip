@@ -76,7 +76,7 @@ __device__ __forceinline__ bf16x8 stage_round(const Stage<float>& s) {
 }
 __device__ __forceinline__ bf16x8 stage_round(const Stage<unsigned short>& s) { return s.v; }
 
-template <int BM, int BN, int BK, int NSPLIT, typename TA, typename TW>
+template <int BM, int BN, int BK, int NSPLIT, typename TA, typename TW, int DEPTH>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int CPR = BK / 8;        // 16-B chunks per LDS row
     constexpr int RB = BK * 2;         // LDS row bytes
@@ -153,8 +153,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         w_base[i] = (long)n * p.ldw;
     }
 
-    Stage<TA> sa[A_IT];
-    Stage<TW> sw[W_IT];
+    // DEPTH register staging sets = global-load prefetch distance in K-tiles.  DEPTH 1 is the
+    // plain double-buffered loop; skinny problems (few MFMAs per tile) are load-latency-bound and
+    // run with DEPTH 4 so that three tiles of loads are always in flight.
+    Stage<TA> sa[DEPTH][A_IT];
+    Stage<TW> sw[DEPTH][W_IT];
+    unsigned okmask[DEPTH];
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -165,116 +169,151 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lh = lane >> 5;
-    unsigned okmask = 0;
 
 #define LDS_OFF(r, c) ((r) * RB + ((((c) ^ (((r) / RPB) % CPR))) << 4))
 
-    // software pipeline, each stage written once: iteration kt issues the global loads of tile
-    // kt+1, runs the MFMAs of tile kt from LDS, then parks tile kt+1 in the other LDS buffer.
-    for (int kt = -1; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) {
-            // ---- issue global loads of tile kt+1 into registers ----
-            const int k0 = kb + (kt + 1) * BK;
-            int tap_dy = 0, tap_dx = 0, cin0 = k0;
-            if (p.a_mode != 0) {
-                int tap = k0 / p.cC;
-                cin0 = k0 - tap * p.cC;
-                int ky = tap / p.KW;
-                int kx = tap - ky * p.KW;
-                tap_dy = ky * p.dil;
-                tap_dx = kx * p.dil;
-            }
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                const int kk = k0 + a_c[i] * 8;
-                bool ok = a_ok[i] && kk < ke;
-                long off;
-                if (p.a_mode == 0) {
-                    off = a_base[i] + kk;
-                } else {
-                    int iy = a_iy0[i] + tap_dy, ix = a_ix0[i] + tap_dx;
-                    ok = ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
-                    off = ((a_base[i] * p.cH + iy) * p.cW + ix) * p.lda + cin0 + a_c[i] * 8;
-                }
-                stage_load(sa[i], reinterpret_cast<const TA*>(p.A) + (ok ? off : 0));
-                okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
-            }
-#pragma unroll
-            for (int i = 0; i < W_IT; ++i) {
-                const int kk = k0 + w_c[i] * 8;
-                const bool ok = w_ok[i] && kk < ke;
-                stage_load(sw[i], reinterpret_cast<const TW*>(p.W) + (ok ? (w_base[i] + kk) : 0));
-                okmask = ok ? (okmask | (1u << (16 + i))) : (okmask & ~(1u << (16 + i)));
-            }
-        }
-        if (kt >= 0) {
-            // ---- MFMAs of tile kt ----
-            const char* ab = smem + (kt & 1) * BUF;
-            const char* wb = ab + NPL * A_PLANE;
-#pragma unroll
-            for (int s = 0; s < BK / 16; ++s) {
-                bf16x8 a_hi[MT], w_hi[NT], a_lo[MT], w_lo[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int row = wr * WM + i * 32 + l31;
-                    const int o = LDS_OFF(row, 2 * s + lh);
-                    a_hi[i] = *reinterpret_cast<const bf16x8*>(ab + o);
-                    if (NSPLIT == 3) a_lo[i] = *reinterpret_cast<const bf16x8*>(ab + A_PLANE + o);
-                }
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int row = wc * WN + j * 32 + l31;
-                    const int o = LDS_OFF(row, 2 * s + lh);
-                    w_hi[j] = *reinterpret_cast<const bf16x8*>(wb + o);
-                    if (NSPLIT == 3) w_lo[j] = *reinterpret_cast<const bf16x8*>(wb + W_PLANE + o);
-                }
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        if (NSPLIT == 3) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], w_hi[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], w_lo[j], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], w_hi[j], acc[i][j], 0, 0, 0);
-                    }
-            }
-        }
-        if (more) {
-            // ---- park tile kt+1 in LDS ----
-            char* base = smem + ((kt + 1) & 1) * BUF;
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                const int o = LDS_OFF(a_r[i], a_c[i]);
-                stage_mask(sa[i], (okmask >> i) & 1u);
-                if (NSPLIT == 3) {
-                    bf16x8 hi, lo;
-                    stage_split(sa[i], hi, lo);
-                    *reinterpret_cast<bf16x8*>(base + o) = hi;
-                    *reinterpret_cast<bf16x8*>(base + A_PLANE + o) = lo;
-                } else {
-                    *reinterpret_cast<bf16x8*>(base + o) = stage_round(sa[i]);
-                }
-            }
-            char* wbw = base + NPL * A_PLANE;
-#pragma unroll
-            for (int i = 0; i < W_IT; ++i) {
-                const int o = LDS_OFF(w_r[i], w_c[i]);
-                stage_mask(sw[i], (okmask >> (16 + i)) & 1u);
-                if (NSPLIT == 3) {
-                    bf16x8 hi, lo;
-                    stage_split(sw[i], hi, lo);
-                    *reinterpret_cast<bf16x8*>(wbw + o) = hi;
-                    *reinterpret_cast<bf16x8*>(wbw + W_PLANE + o) = lo;
-                } else {
-                    *reinterpret_cast<bf16x8*>(wbw + o) = stage_round(sw[i]);
-                }
-            }
-        }
-        __syncthreads();
+// issue the global loads of K-tile T into register set SET (unconditional loads, clamped address)
+#define ISSUE_TILE(T, SET)                                                                              \
+    {                                                                                                   \
+        const int k0 = kb + (T) * BK;                                                                   \
+        int tap_dy = 0, tap_dx = 0, cin0 = k0;                                                          \
+        if (p.a_mode != 0) {                                                                            \
+            int tap = k0 / p.cC;                                                                        \
+            cin0 = k0 - tap * p.cC;                                                                     \
+            int ky = tap / p.KW;                                                                        \
+            int kx = tap - ky * p.KW;                                                                   \
+            tap_dy = ky * p.dil;                                                                        \
+            tap_dx = kx * p.dil;                                                                        \
+        }                                                                                               \
+        unsigned okm = 0;                                                                               \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                              \
+            const int kk = k0 + a_c[i] * 8;                                                             \
+            bool ok = a_ok[i] && kk < ke;                                                               \
+            long off;                                                                                   \
+            if (p.a_mode == 0) {                                                                        \
+                off = a_base[i] + kk;                                                                   \
+            } else {                                                                                    \
+                int iy = a_iy0[i] + tap_dy, ix = a_ix0[i] + tap_dx;                                     \
+                ok = ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;                                \
+                off = ((a_base[i] * p.cH + iy) * p.cW + ix) * p.lda + cin0 + a_c[i] * 8;                \
+            }                                                                                           \
+            stage_load(sa[SET][i], reinterpret_cast<const TA*>(p.A) + (ok ? off : 0));                  \
+            okm |= ok ? (1u << i) : 0u;                                                                 \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < W_IT; ++i) {                                              \
+            const int kk = k0 + w_c[i] * 8;                                                             \
+            const bool ok = w_ok[i] && kk < ke;                                                         \
+            stage_load(sw[SET][i], reinterpret_cast<const TW*>(p.W) + (ok ? (w_base[i] + kk) : 0));     \
+            okm |= ok ? (1u << (16 + i)) : 0u;                                                          \
+        }                                                                                               \
+        okmask[SET] = okm;                                                                              \
     }
+
+// park register set SET (K-tile T) in LDS buffer T & 1, splitting / rounding on the way
+#define PARK_TILE(T, SET)                                                                               \
+    {                                                                                                   \
+        char* base = smem + ((T) & 1) * BUF;                                                            \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                              \
+            const int o = LDS_OFF(a_r[i], a_c[i]);                                                      \
+            stage_mask(sa[SET][i], (okmask[SET] >> i) & 1u);                                            \
+            if (NSPLIT == 3) {                                                                          \
+                bf16x8 hi, lo;                                                                          \
+                stage_split(sa[SET][i], hi, lo);                                                        \
+                *reinterpret_cast<bf16x8*>(base + o) = hi;                                              \
+                *reinterpret_cast<bf16x8*>(base + A_PLANE + o) = lo;                                    \
+            } else {                                                                                    \
+                *reinterpret_cast<bf16x8*>(base + o) = stage_round(sa[SET][i]);                         \
+            }                                                                                           \
+        }                                                                                               \
+        char* wbw = base + NPL * A_PLANE;                                                               \
+        _Pragma("unroll") for (int i = 0; i < W_IT; ++i) {                                              \
+            const int o = LDS_OFF(w_r[i], w_c[i]);                                                      \
+            stage_mask(sw[SET][i], (okmask[SET] >> (16 + i)) & 1u);                                     \
+            if (NSPLIT == 3) {                                                                          \
+                bf16x8 hi, lo;                                                                          \
+                stage_split(sw[SET][i], hi, lo);                                                        \
+                *reinterpret_cast<bf16x8*>(wbw + o) = hi;                                               \
+                *reinterpret_cast<bf16x8*>(wbw + W_PLANE + o) = lo;                                     \
+            } else {                                                                                    \
+                *reinterpret_cast<bf16x8*>(wbw + o) = stage_round(sw[SET][i]);                          \
+            }                                                                                           \
+        }                                                                                               \
+    }
+
+    // prologue: DEPTH tiles of loads in flight, tile 0 parked
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nkt) ISSUE_TILE(d, d)
+    if (nkt > 0) PARK_TILE(0, 0)
+    __syncthreads();
+
+    // steady state, unrolled by DEPTH so every register-set index is a compile-time constant:
+    // iteration kt re-fills set kt % DEPTH (its tile was parked one iteration ago) with tile
+    // kt + DEPTH, runs the MFMAs of tile kt from LDS, then parks tile kt + 1.
+    for (int kt0 = 0; kt0 < nkt; kt0 += DEPTH) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const int kt = kt0 + j;
+            if (kt < nkt) {
+                if (kt + DEPTH < nkt) ISSUE_TILE(kt + DEPTH, j)
+                {
+                    // ---- MFMAs of tile kt ----
+                    const char* ab = smem + (kt & 1) * BUF;
+                    const char* wb = ab + NPL * A_PLANE;
+#pragma unroll
+                    for (int s = 0; s < BK / 16; ++s) {
+                        bf16x8 a_hi[MT], w_hi[NT], a_lo[MT], w_lo[NT];
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            const int row = wr * WM + i * 32 + l31;
+                            const int o = LDS_OFF(row, 2 * s + lh);
+                            a_hi[i] = *reinterpret_cast<const bf16x8*>(ab + o);
+                            if (NSPLIT == 3) a_lo[i] = *reinterpret_cast<const bf16x8*>(ab + A_PLANE + o);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < NT; ++jj) {
+                            const int row = wc * WN + jj * 32 + l31;
+                            const int o = LDS_OFF(row, 2 * s + lh);
+                            w_hi[jj] = *reinterpret_cast<const bf16x8*>(wb + o);
+                            if (NSPLIT == 3) w_lo[jj] = *reinterpret_cast<const bf16x8*>(wb + W_PLANE + o);
+                        }
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < NT; ++jj) {
+                                if (NSPLIT == 3) {
+                                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], w_hi[jj], acc[i][jj], 0, 0, 0);
+                                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], w_lo[jj], acc[i][jj], 0, 0, 0);
+                                }
+                                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], w_hi[jj], acc[i][jj], 0, 0, 0);
+                            }
+                    }
+                }
+                if (kt + 1 < nkt) PARK_TILE(kt + 1, (j + 1) % DEPTH)
+                __syncthreads();
+            }
+        }
+    }
+#undef ISSUE_TILE
+#undef PARK_TILE
 #undef LDS_OFF
+
+    // ---- split-K: add the raw partial sums straight from the accumulator layout: one register
+    // of a 32x32 tile is 2 rows x 32 consecutive columns = two 128-B segments per wave-instruction,
+    // the shape global float atomics run at full rate in (MI355X_MICROARCH.md, global float atomics)
+    if (p.splitk > 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int n = n0 + wc * WN + j * 32 + l31;
+                    if (m < p.M && n < p.N) atomicAdd(p.partial + (long)m * p.N + n, acc[i][j][r]);
+                }
+        return;
+    }
 
     // ---- epilogue: accumulators -> per-wave LDS tile -> row-contiguous 16-B stores ----
     // (the K loop ended on a barrier, so the staging buffers are free)
@@ -297,22 +336,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         const int m = m0 + wr * WM + row_l;
         if (m >= p.M || n >= p.N) continue;
         const float4 v = *reinterpret_cast<const float4*>(&stg[row_l * WN + col_l]);
-        if (p.splitk > 1) {
-            float* dst = p.partial + (long)m * p.N + n;
-            atomicAdd(dst, v.x);
-            if (n + 1 < p.N) atomicAdd(dst + 1, v.y);
-            if (n + 2 < p.N) atomicAdd(dst + 2, v.z);
-            if (n + 3 < p.N) atomicAdd(dst + 3, v.w);
+        const RowMap rm = row_map(p, m);
+        if (p.vec4) {
+            store_four(p, rm, n, v);
         } else {
-            const RowMap rm = row_map(p, m);
-            if (p.vec4) {
-                store_four(p, rm, n, v);
-            } else {
-                store_one(p, rm, n, v.x);
-                if (n + 1 < p.N) store_one(p, rm, n + 1, v.y);
-                if (n + 2 < p.N) store_one(p, rm, n + 2, v.z);
-                if (n + 3 < p.N) store_one(p, rm, n + 3, v.w);
-            }
+            store_one(p, rm, n, v.x);
+            if (n + 1 < p.N) store_one(p, rm, n + 1, v.y);
+            if (n + 2 < p.N) store_one(p, rm, n + 2, v.z);
+            if (n + 3 < p.N) store_one(p, rm, n + 3, v.w);
         }
     }
 }
@@ -324,15 +355,20 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue(const GemmArgs p) {
         const int m = (int)(idx / p.N);
         const int n = (int)(idx - (long)m * p.N);
         const RowMap rm = row_map(p, m);
-        store_one(p, rm, n, p.partial[idx]);
+        const float v = p.partial[idx];
+        // leave the slab zeroed for the next split-K launch that shares it (no memset per launch)
+        p.partial[idx] = 0.f;
+        store_one(p, rm, n, v);
     }
 }
 
 template <int BM, int BN, int BK, int NSPLIT, typename TA, typename TW>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
+    // 64 x 64 tiles serve the skinny, load-latency-bound shapes: prefetch 4 K-tiles deep
+    constexpr int DEPTH = (BM == 64 && BN == 64) ? 4 : 1;
     constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
     constexpr size_t lds = 2ull * NPL * (BM + BN) * BK * 2;
-    auto kfn = gemm_kernel<BM, BN, BK, NSPLIT, TA, TW>;
+    auto kfn = gemm_kernel<BM, BN, BK, NSPLIT, TA, TW, DEPTH>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -452,7 +488,9 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
             return SKIMI_ERR_WORKSPACE;
         }
         a.partial = (float*)scratch;
-        SKIMI_HIP(hipMemsetAsync(scratch, 0, need, st));
+        // the split-K epilogue re-zeroes what it reads, so a caller that zeroed the slab once
+        // (splitk_scratch_zeroed) pays no memset per launch
+        if (!d->splitk_scratch_zeroed) SKIMI_HIP(hipMemsetAsync(scratch, 0, need, st));
     }
 
     int rc;

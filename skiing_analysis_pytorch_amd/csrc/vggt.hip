@@ -334,6 +334,7 @@ struct Ctx {
         d.A = A; d.a_dtype = a_dt; d.lda = lda;
         d.W = L.w; d.w_dtype = L.wdt; d.ldw = L.K;
         d.prec = L.prec;
+        d.splitk_scratch_zeroed = 1;
         d.W_split = M >= 4096 ? L.w_split : nullptr;
         d.bias = L.b;
         d.out = out; d.out_dtype = out_dt; d.ldo = ldo;
@@ -689,6 +690,8 @@ int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query,
     // split-K slab: large enough for the skinny camera-head / small-config GEMMs
     c.slab_bytes = std::max<size_t>((size_t)F * 6 * C * 4 * 4, 1u << 20);
     c.slab = c.ar.alloc(c.slab_bytes);
+    // zeroed once per forward; every split-K epilogue leaves the slab zero again
+    if (!c.dry() && hipMemsetAsync(c.slab, 0, c.slab_bytes, c.st) != hipSuccess) c.rc = SKIMI_ERR_HIP;
 
     float* x = (float*)c.ar.alloc((size_t)M * C * 4);
     // kept intermediates

@@ -248,6 +248,8 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
     d.out_dtype = SKIMI_F32;
     d.splitk_scratch = slab;
     d.splitk_scratch_bytes = actb;
+    d.splitk_scratch_zeroed = 1;   // zeroed once here; every split-K epilogue leaves it zero again
+    SKIMI_HIP(hipMemsetAsync(slab, 0, actb, st));
     d.act = SKIMI_ACT_RELU;
 
     // expand: [B*L0, k0pad] x [C, k0pad]^T

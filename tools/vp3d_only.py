@@ -1,0 +1,10 @@
+import sys, torch
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from skiing_analysis_pytorch_amd import vp3d, weights as W
+from skiing_analysis_pytorch_amd._lib import PREC_BF16X3
+m = vp3d.TemporalModel(17, 2, 17, [3,3,3], prec=PREC_BF16X3)
+m.load_state_dict(W.make_vp3d_state_dict(seed=0, filter_widths=[3,3,3]))
+x = torch.randn(2, 269, 17, 2, device="cuda")
+for _ in range(5): m(x)
+torch.cuda.synchronize()
