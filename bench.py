@@ -76,9 +76,21 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.rand((B, S_VIEWS, 3, IMG, IMG), generator=g, device=dev, dtype=torch.float32)
     want = {"camera", "depth", "point"}
+    # 2D keypoints of the 17 joints in every view (the reference reads them from the clip's .pt file)
+    kps = torch.rand((B, S_VIEWS, 17, 2), generator=g, device=dev, dtype=torch.float32) * (IMG - 40) + 20
+    from skiing_analysis_pytorch_amd import geometry, parallel
 
     def step():
-        return model(images, want=want)
+        # VGGT forward (all three heads, as `self.vggt(imgs)` computes them) -> cameras -> DLT
+        # triangulation of the joints over the 8 views -> [B, 17, 3]; under torch.distributed the
+        # per-rank joints are re-assembled with the path's one collective (all-gather over xGMI)
+        out = model(images, want=want)
+        E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (IMG, IMG))
+        joints = geometry.triangulate_joints(K, E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous(), kps)
+        if use_dist:
+            joints = parallel.all_gather_steps(joints, world * B)
+        out["joints3d"] = joints
+        return out
 
     for _ in range(args.warmup):
         step()
@@ -104,7 +116,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(out["pose_enc"]).all()
+    assert torch.isfinite(out["pose_enc"]).all() and out["joints3d"].shape == (world * B, 17, 3)
 
     frames = world * args.steps * B
     value = frames / elapsed
@@ -121,7 +133,8 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": "VGGT-1B multi_view_process step: 8 views x 518x518, camera+depth+point heads",
+        "config": {"workload": "VGGT-1B multi_view_process step: 8 views x 518x518, camera+depth+point heads, "
+                               "pose->cameras + 8-view DLT of 17 joints (+ all-gather of the joints across ranks)",
                    "views": S_VIEWS, "image": IMG, "time_steps_per_call": B, "parallelism": f"clip-dp{world}",
                    "aggregator_prec": "bf16 MFMA, fp32 accumulate/residual/LayerNorm/softmax",
                    "head_prec": "bf16x3 (fp32-accurate)"},
