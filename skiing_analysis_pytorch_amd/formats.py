@@ -1,0 +1,93 @@
+"""On-disk formats either side of the hot path.
+
+Input: the per-clip `.pt` written by the reference's prepare_dataset stage
+(prepare_dataset/main.py:53-98, process/preprocess.py:160-171):
+    {video_name, video_path, frame_count, img_shape, fps,
+     detectron2: {bbox [T,4] | [T,N,4], keypoints [T,17,2|3], keypoints_score [T,17]}, yolo: {...}, depth?, frames?}
+read as the reference's loaders do (vggt/load.py:268-370 `load_info`,
+VideoPose3D/common/custom_dataset.py:106-164), minus the video decode: torchvision / PyAV are
+not part of this build, so frames come from the `.pt` itself when present or from the caller.
+
+Output: `.npy [T,17,3]` of the lifter (VideoPose3D/run.py:1089-1092) and the camera NPZ of the
+VGGT stage (vggt/save.py:84-110, `infer.save_camera_info`).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def _load_pt(path) -> dict:
+    # only loaders that execute nothing from the file
+    return torch.load(str(path), map_location="cpu", weights_only=True)
+
+
+def _to_numpy_xy(kpts) -> np.ndarray:
+    a = kpts.detach().cpu().numpy() if isinstance(kpts, torch.Tensor) else np.asarray(kpts)
+    return a[..., :2].astype(np.float32)
+
+
+def load_info(pt_file_path, frames: Optional[torch.Tensor] = None, assume_normalized: Optional[bool] = None,
+              clip_bbox_to_image: bool = True, dtype=np.float32) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, Optional[torch.Tensor]]:
+    """vggt/load.py:268-370.  Returns (keypoints_xy [T,K,2] pixels, keypoints_score [T,K],
+    bboxes_xyxy [T,4|N,4] pixels, bbox_scores, frames [T,H,W,3] uint8 | None)."""
+    data = _load_pt(pt_file_path)
+    if "detectron2" not in data:
+        raise KeyError(f"pt file missing 'detectron2' root: {pt_file_path}")
+    d2 = data["detectron2"]
+    if frames is None and "frames" in data and data["frames"] is not None:
+        frames = data["frames"]
+    if frames is not None:
+        H, W = int(frames.shape[1]), int(frames.shape[2])
+    elif "img_shape" in data:
+        H, W = int(data["img_shape"][0]), int(data["img_shape"][1])
+    else:
+        raise KeyError("neither frames nor img_shape available to de-normalise the keypoints")
+    if "keypoints" not in d2:
+        raise KeyError(f"pt file missing detectron2.keypoints: {pt_file_path}")
+    kpts_t = d2["keypoints"]
+    kpts_xy = _to_numpy_xy(kpts_t)
+    mx = np.nanmax(kpts_xy) if kpts_xy.size else 0.0
+    if assume_normalized is True or (assume_normalized is None and mx <= 1.5):
+        kpts_xy = kpts_xy * np.array([W, H], dtype=np.float32)
+    if "keypoints_score" in d2:
+        kpt_scores = np.asarray(d2["keypoints_score"].detach().cpu().numpy() if isinstance(d2["keypoints_score"], torch.Tensor) else d2["keypoints_score"])
+    elif kpts_t.shape[-1] >= 3:
+        kpt_scores = np.asarray(kpts_t[..., 2])
+    else:
+        kpt_scores = np.ones(kpts_xy.shape[:2], dtype=dtype)
+    if kpts_xy.ndim != 3 or kpts_xy.shape[2] != 2:
+        raise ValueError(f"Invalid D2 keypoints shape after processing: {kpts_xy.shape}")
+    if kpt_scores.shape != kpts_xy.shape[:2]:
+        raise ValueError(f"D2 keypoints_score shape {kpt_scores.shape} mismatches keypoints {kpts_xy.shape}")
+    if "bbox" not in d2:
+        raise KeyError(f"pt file missing detectron2.bbox: {pt_file_path}")
+    bb = d2["bbox"]
+    bboxes = (bb.detach().cpu().numpy() if isinstance(bb, torch.Tensor) else np.asarray(bb)).astype(dtype, copy=True)
+    mxb = np.nanmax(bboxes) if bboxes.size else 0.0
+    if assume_normalized is True or (assume_normalized is None and mxb <= 1.5):
+        bboxes[..., 0::2] *= float(W)
+        bboxes[..., 1::2] *= float(H)
+    if "scores" in d2:
+        bbox_scores = np.asarray(d2["scores"], dtype=dtype)
+    elif "bbox_score" in d2:
+        bbox_scores = np.asarray(d2["bbox_score"], dtype=dtype)
+    else:
+        bbox_scores = np.ones(bboxes.shape[:-1], dtype=dtype)
+    if clip_bbox_to_image:
+        x1 = np.minimum(bboxes[..., 0], bboxes[..., 2]); x2 = np.maximum(bboxes[..., 0], bboxes[..., 2])
+        y1 = np.minimum(bboxes[..., 1], bboxes[..., 3]); y2 = np.maximum(bboxes[..., 1], bboxes[..., 3])
+        bboxes = np.stack([np.clip(x1, 0, W - 1), np.clip(y1, 0, H - 1), np.clip(x2, 0, W - 1), np.clip(y2, 0, H - 1)], axis=-1)
+    return (kpts_xy.astype(dtype, copy=False), kpt_scores.astype(dtype, copy=False), bboxes.astype(dtype, copy=False),
+            bbox_scores.astype(dtype, copy=False), frames)
+
+
+def save_pose_npy(path, prediction: np.ndarray) -> Path:
+    """VideoPose3D/run.py:1089-1092: `<video>.npy` holding [T, 17, 3] float32 camera-space joints."""
+    p = Path(path)
+    p.parent.mkdir(parents=True, exist_ok=True)
+    np.save(p, np.asarray(prediction, dtype=np.float32))
+    return p if p.suffix == ".npy" else p.with_suffix(p.suffix + ".npy")

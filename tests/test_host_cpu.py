@@ -99,3 +99,28 @@ def test_load_and_preprocess_images_shapes():
         load_and_preprocess_images([])
     with pytest.raises(ValueError):
         load_and_preprocess_images(imgs, mode="stretch")
+
+
+def test_pt_clip_loader_roundtrip(tmp_path):
+    """the `.pt` clip format of prepare_dataset, read as vggt/load.py:268-370 does."""
+    from skiing_analysis_pytorch_amd import formats
+
+    T, H, W = 5, 108, 192
+    g = torch.Generator().manual_seed(0)
+    kp = torch.rand((T, 17, 3), generator=g)                    # normalised x, y + score
+    bbox = torch.tensor([[0.6, 0.2, 0.3, 0.9]]).repeat(T, 1)    # x1 > x2 on purpose
+    pt = {"video_name": "clip", "frame_count": T, "img_shape": (H, W), "fps": 30,
+          "detectron2": {"keypoints": kp, "bbox": bbox},
+          "frames": torch.zeros((T, H, W, 3), dtype=torch.uint8)}
+    f = tmp_path / "clip.pt"
+    torch.save(pt, f)
+    xy, sc, bb, bs, frames = formats.load_info(f)
+    assert xy.shape == (T, 17, 2) and sc.shape == (T, 17) and frames.shape == (T, H, W, 3)
+    np.testing.assert_allclose(xy, kp[..., :2].numpy() * np.array([W, H], dtype=np.float32), rtol=1e-6)
+    np.testing.assert_allclose(sc, kp[..., 2].numpy())
+    assert (bb[:, 0] <= bb[:, 2]).all() and bb[:, 2].max() <= W - 1          # sorted and clipped
+    with pytest.raises(KeyError):
+        torch.save({"yolo": {}}, tmp_path / "bad.pt")
+        formats.load_info(tmp_path / "bad.pt")
+    out = formats.save_pose_npy(tmp_path / "pose.npy", np.zeros((T, 17, 3)))
+    assert np.load(out).shape == (T, 17, 3)
