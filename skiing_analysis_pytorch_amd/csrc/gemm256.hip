@@ -21,8 +21,8 @@ namespace skimi {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
-// EPI: 0 = generic epilogue (runtime flags); 1 = bias (+act) -> bf16 rows (qkv, fc1);
-//      2 = bias, LayerScale, fp32 residual -> fp32 rows, plain row map (proj, fc2)
+// EPI: 0 = generic epilogue (runtime flags); 1 = bias -> bf16 rows (qkv); 3 = bias, GELU -> bf16
+//      rows (fc1); 2 = bias, LayerScale, fp32 residual -> fp32 rows, plain row map (proj, fc2)
 template <int MT, int EPI>   // M tiles of 32 rows per wave: BM = 64 * MT (192 or 256)
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     constexpr int BM = 64 * MT, BN = 256, BK = 64;
@@ -46,6 +46,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     const int tm = id / p.ntn, tn = id - tm * p.ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = p.K / BK;
+    if ((p.dbg & 16) && blockIdx.x < 256) {
+        // experiment: de-phase the CUs so epilogue store bursts overlap other CUs' main loops
+        const long long t0 = wall_clock64();
+        const long long wait = (long long)((blockIdx.x >> 3) & 3) * (nkt * 50 + 300) / 4;
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
 
     // staging: wave-instruction j of this wave covers tile rows 8*(4*wave + j) .. +7;
     // lane -> (row = lane>>3, LDS chunk = lane&7), source chunk = LDS chunk ^ ((row>>1)&7)
@@ -152,18 +158,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int m = m0 + wr * (32 * MT) + i * 32 + it * 4 + (lane >> 4);
-                    if (m < p.M) {
+                    if (m < p.M && !(p.dbg & 4)) {
                         float y0 = v[it].x + bs.x, y1 = v[it].y + bs.y, y2 = v[it].z + bs.z, y3 = v[it].w + bs.w;
-                        if (EPI == 1) {
-                            y0 = apply_act(y0, p.act); y1 = apply_act(y1, p.act);
-                            y2 = apply_act(y2, p.act); y3 = apply_act(y3, p.act);
+                        if (EPI == 1 || EPI == 3) {
+                            if (EPI == 3) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
                             bf16x4 hb;
                             hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
-                            *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)m * p.ldo + n) = hb;
+                            bf16x4* dst = reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)m * p.ldo + n);
+                            if (p.dbg & 8) __builtin_nontemporal_store(hb, dst); else *dst = hb;
                         } else {
                             const float4 r = *reinterpret_cast<const float4*>((const float*)p.resid + (long)m * p.ldr + n);
-                            *reinterpret_cast<float4*>((float*)p.out + (long)m * p.ldo + n) =
-                                make_float4(r.x + gm.x * y0, r.y + gm.y * y1, r.z + gm.z * y2, r.w + gm.w * y3);
+                            f32x4 ov = {r.x + gm.x * y0, r.y + gm.y * y1, r.z + gm.z * y2, r.w + gm.w * y3};
+                            f32x4* dst = reinterpret_cast<f32x4*>((float*)p.out + (long)m * p.ldo + n);
+                            if (p.dbg & 8) __builtin_nontemporal_store(ov, dst); else *dst = ov;
                         }
                     }
                 }
@@ -195,7 +202,11 @@ static int epi_kind(const GemmArgs& a) {
     const bool plain = a.vec4 && a.store_mode == 0 && a.out_rpb == 0 && a.out_off == 0 && a.out2 == nullptr &&
                        a.resid2 == nullptr && a.post_act == SKIMI_ACT_NONE && a.N % 4 == 0;
     if (!plain) return 0;
-    if (a.out_dtype == SKIMI_BF16 && a.gamma == nullptr && a.resid == nullptr) return 1;
+    if (a.out_dtype == SKIMI_BF16 && a.gamma == nullptr && a.resid == nullptr) {
+        if (a.act == SKIMI_ACT_NONE) return 1;
+        if (a.act == SKIMI_ACT_GELU) return 3;
+        return 0;
+    }
     if (a.out_dtype == SKIMI_F32 && a.gamma != nullptr && a.resid != nullptr && a.resid_dtype == SKIMI_F32 &&
         a.resid_rpb == 0 && a.resid_off == 0 && a.act == SKIMI_ACT_NONE)
         return 2;
@@ -241,10 +252,12 @@ int gemm256_launch(GemmArgs& a, hipStream_t st) {
     const int epi = epi_kind(a);
     if (cost(192) < cost(256)) {
         if (epi == 1) return launch256<3, 1>(a, st);
+        if (epi == 3) return launch256<3, 3>(a, st);
         if (epi == 2) return launch256<3, 2>(a, st);
         return launch256<3, 0>(a, st);
     }
     if (epi == 1) return launch256<4, 1>(a, st);
+    if (epi == 3) return launch256<4, 3>(a, st);
     if (epi == 2) return launch256<4, 2>(a, st);
     return launch256<4, 0>(a, st);
 }

@@ -41,12 +41,30 @@ struct GemmArgs {
     int dbg;           // diagnostics only (gemm256 ablation: bit0 skip staging, bit1 skip MFMA phase)
 };
 
+// erf-GELU with erfc by Abramowitz & Stegun 7.1.26 (|err| <= 1.5e-7 absolute, i.e. fp32 rounding
+// level on O(1) activations): branch-free, ~16 VALU ops.  libm's erff/expf inline to ~1 KB of
+// branchy code per call site, which pushed the unrolled GEMM epilogues past the 64-KiB
+// instruction cache (gemm256 bias+GELU epilogue: 110 KB of code, ~3x slower stores).
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
+    float q = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    q = __builtin_fmaf(t, q, 1.421413741f);
+    q = __builtin_fmaf(t, q, -0.284496736f);
+    q = __builtin_fmaf(t, q, 0.254829592f);
+    q = q * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z) * 0.5f;   // 0.5 * erfc(|z|)
+    return v >= 0.f ? __builtin_fmaf(-v, q, v) : v * q;
+}
+// 1 / (1 + e^-v) on the hardware exp2 / rcp units (1 ulp each)
+__device__ __forceinline__ float sigmoid_hw(float v) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case SKIMI_ACT_RELU: return fmaxf(v, 0.f);
-        case SKIMI_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        case SKIMI_ACT_SILU: return v / (1.f + expf(-v));
-        case SKIMI_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case SKIMI_ACT_GELU: return gelu_erf(v);
+        case SKIMI_ACT_SILU: return v * sigmoid_hw(v);
+        case SKIMI_ACT_SIGMOID: return sigmoid_hw(v);
         default: return v;
     }
 }
