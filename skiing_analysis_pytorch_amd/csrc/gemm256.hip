@@ -21,6 +21,135 @@ namespace skimi {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
+// blockIdx -> output tile.  Workgroups are dealt to the 8 XCDs round-robin, so the blocks with equal
+// blockIdx & 7 share an L2: give each XCD a contiguous run of tile ids (bijective for any count),
+// and order the ids so that the ~32 tiles an XCD runs at once form an 8-row x 4-column patch
+// (groups of 8 tile rows, column-major inside a group): per K-step that patch pulls 8 A panels and
+// 4 W panels through the L2 instead of 2-3 A panels and every W panel (row-major order), which is
+// what bounds the LDS-DMA stream.
+__device__ __forceinline__ void tile_coords256(const GemmArgs& p, int& tm, int& tn) {
+    const int nblk = p.ntm * p.ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GM = 8;
+    const int per_group = GM * p.ntn;
+    const int group = id / per_group, within = id - group * per_group;
+    const int rows = min(GM, p.ntm - group * GM);
+    tn = within / rows;
+    tm = group * GM + within - tn * rows;
+}
+
+// Epilogue shared by both main loops: MT passes of 32 rows through this wave's private 8-KiB LDS
+// slab -> row-contiguous 16-B (fp32) / 8-B (bf16) stores.  The caller guarantees that no wave
+// still reads operand tiles from LDS (the slabs alias buffer 0).
+//
+// Stores share the vmcnt counter with loads on gfx9, and hipcc cannot count across branches: a
+// per-row `if (m < M)` turns into s_cbranch_execz + s_waitcnt vmcnt(0) per row, i.e. every store
+// waits for the previous one's round trip.  So the interior tiles (all but the last tile row /
+// column) take a branch-free straight-line path, and only edge tiles run the checked loop.
+template <int MT, int EPI>
+__device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT][2], char* smem, int wave, int lane,
+                                            int wr, int wc, int m0, int n0) {
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+    const int n = n0 + wc * 64 + 4 * (lane & 15);
+    const bool interior = (m0 + 64 * MT <= p.M) && (n0 + 256 <= p.N) && !(p.dbg & 4);   // block-uniform
+    float4 bs = make_float4(0, 0, 0, 0), gm = make_float4(1, 1, 1, 1);
+    if (EPI != 0 && n < p.N) {
+        if (p.bias) bs = *reinterpret_cast<const float4*>(p.bias + n);
+        if (EPI == 2) gm = *reinterpret_cast<const float4*>(p.gamma + n);
+    }
+    // accumulators of row block i -> this wave's slab.  Same-wave LDS write -> read: DS ops of one
+    // wave execute in order; the compiler only needs to keep them in program order.
+#define SKIMI_ACC_TO_SLAB(i)                                                                                   \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r)            \
+            stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + j * 32 + l31] = acc[i][j][r];                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                  \
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                    \
+    } while (0)
+
+    if (EPI != 0 && interior) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            SKIMI_ACC_TO_SLAB(i);
+            const int mrow = m0 + wr * (32 * MT) + i * 32 + (lane >> 4);
+            float4 v[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                v[it] = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + 4 * (lane & 15)]);
+            if (EPI == 2) {
+                float4 r[8];
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    r[it] = *reinterpret_cast<const float4*>((const float*)p.resid + (long)(mrow + it * 4) * p.ldr + n);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    f32x4 ov = {r[it].x + gm.x * (v[it].x + bs.x), r[it].y + gm.y * (v[it].y + bs.y),
+                                r[it].z + gm.z * (v[it].z + bs.z), r[it].w + gm.w * (v[it].w + bs.w)};
+                    *reinterpret_cast<f32x4*>((float*)p.out + (long)(mrow + it * 4) * p.ldo + n) = ov;
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    float y0 = v[it].x + bs.x, y1 = v[it].y + bs.y, y2 = v[it].z + bs.z, y3 = v[it].w + bs.w;
+                    if (EPI == 3) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
+                    bf16x4 hb;
+                    hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
+                    *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)(mrow + it * 4) * p.ldo + n) = hb;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // slab reads retired before the next pass overwrites it
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        SKIMI_ACC_TO_SLAB(i);
+        const int mrow = m0 + wr * (32 * MT) + i * 32 + (lane >> 4);
+        if (EPI != 0) {
+            // edge tiles: checked, rolled loop
+#pragma unroll 1
+            for (int it = 0; it < 8; ++it) {
+                const int m = mrow + it * 4;
+                if (m >= p.M || n >= p.N || (p.dbg & 4)) continue;
+                const float4 v = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + 4 * (lane & 15)]);
+                float y0 = v.x + bs.x, y1 = v.y + bs.y, y2 = v.z + bs.z, y3 = v.w + bs.w;
+                if (EPI == 2) {
+                    const float4 r = *reinterpret_cast<const float4*>((const float*)p.resid + (long)m * p.ldr + n);
+                    f32x4 ov = {r.x + gm.x * y0, r.y + gm.y * y1, r.z + gm.z * y2, r.w + gm.w * y3};
+                    *reinterpret_cast<f32x4*>((float*)p.out + (long)m * p.ldo + n) = ov;
+                } else {
+                    if (EPI == 3) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
+                    bf16x4 hb;
+                    hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
+                    *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)m * p.ldo + n) = hb;
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < 8; ++it) {
+                const int m = mrow + it * 4;
+                if (m >= p.M || n >= p.N) continue;
+                const float4 v = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + 4 * (lane & 15)]);
+                const RowMap rm = row_map(p, m);
+                if (p.vec4) {
+                    store_four(p, rm, n, v);
+                } else {
+                    store_one(p, rm, n, v.x);
+                    if (n + 1 < p.N) store_one(p, rm, n + 1, v.y);
+                    if (n + 2 < p.N) store_one(p, rm, n + 2, v.z);
+                    if (n + 3 < p.N) store_one(p, rm, n + 3, v.w);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+#undef SKIMI_ACC_TO_SLAB
+}
+
 // EPI: 0 = generic epilogue (runtime flags); 1 = bias -> bf16 rows (qkv); 3 = bias, GELU -> bf16
 //      rows (fc1); 2 = bias, LayerScale, fp32 residual -> fp32 rows, plain row map (proj, fc2)
 template <int MT, int EPI>   // M tiles of 32 rows per wave: BM = 64 * MT (192 or 256)
@@ -35,15 +164,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     const int wr = wave >> 2, wc = wave & 3;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    int id;
-    {
-        const int nblk = p.ntm * p.ntn;
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7;
-        const int q = nblk >> 3, r = nblk & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = id / p.ntn, tn = id - tm * p.ntn;
+    int tm, tn;
+    tile_coords256(p, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = p.K / BK;
     if ((p.dbg & 16) && blockIdx.x < 256) {
@@ -132,70 +254,179 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: MT passes of 32 rows through this wave's private 8-KiB LDS slab ----
-    float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
-    const int n = n0 + wc * 64 + 4 * (lane & 15);
+    epilogue256<MT, EPI>(p, acc, smem, wave, lane, wr, wc, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ping-pong main loop (256x256 tile only).  The two waves that share a SIMD (wr = 0 / wr = 1)
+// run half a phase apart: while one issues its 8 MFMAs of a 64x32 output quadrant, the other
+// reads the fragments of its next quadrant from LDS and issues its share of the LDS-DMA
+// prefetch, then they swap at a raw s_barrier.  No vmcnt(0) and no fence inside the loop: the
+// DMA of K-tile kt+2 is issued into the buffer of K-tile kt quarter by quarter, each quarter two
+// or more barriers after its last reader, and retired by ONE counted s_waitcnt per K-tile.
+//
+// A K-tile (BK = 64) is staged as four 16-KiB quarter tiles, named by the phase that reads them:
+//   HA[ih] : A rows 64*ih + {0..63} of both wave rows   (quadrants (ih, *))
+//   HW[jh] : W rows 64*wc + 32*jh + {0..31}, wc = 0..3  (quadrants (*, jh))
+// phase order (0,0) (0,1) (1,1) (1,0); fragment reads: P1 A[0] + W[0], P2 W[1], P3 A[1], P4 none
+// (both W halves stay in registers).  DMA issue, two wave-instructions per wave and phase:
+//   P1: HA[1](kt+1)   P2: HW[0](kt+1)   P3: HA[0](kt+2)   P4: HW[1](kt+2), then vmcnt(4):
+// everything but the two quarters just issued has landed, i.e. all of K-tile kt+1.
+// WAR distance: HA[0](kt) is last read in P1 and overwritten from P3 (4+ barriers later), HW[1]
+// P2 -> P4, HA[1] P3 -> next P1, HW[0] P1 -> next P2.
+#define SKIMI_BAR()                           \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at their maxima)
+#define SKIMI_VMCNT(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GemmArgs p) {
+    constexpr int MT = 4, BM = 256, BN = 256, BK = 64;
+    constexpr int RB = 128;
+    constexpr int A_TILE = BM * RB, W_TILE = BN * RB, BUF = A_TILE + W_TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int tm, tn;
+    tile_coords256(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nkt = p.K / BK;
+
+    // DMA pieces: quarter tile = 16 wave-instructions (8 rows x 128 B each); this wave issues
+    // pieces g = 2*wave + j.  lane -> (row = lane>>3, LDS chunk = lane&7), source chunk swizzled.
+    const unsigned short* A = (const unsigned short*)p.A;
+    const unsigned short* W = (const unsigned short*)p.W;
+    const unsigned short* a_src[2][2];   // [ih][j]
+    const unsigned short* w_src[2][2];   // [jh][j]
+    int a_row0[2][2], w_row0[2][2];      // wave-uniform first tile row of the piece
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int g = 2 * wave + j;
+            a_row0[h][j] = (g >> 3) * 128 + 64 * h + 8 * (g & 7);
+            w_row0[h][j] = (g >> 2) * 64 + 32 * h + 8 * (g & 3);
+            int row = a_row0[h][j] + (lane >> 3);
+            int c = (lane & 7) ^ ((row >> 1) & 7);
+            a_src[h][j] = A + (long)min(((p.dbg & 64) ? 0 : m0) + row, p.M - 1) * p.lda + c * 8;
+            row = w_row0[h][j] + (lane >> 3);
+            c = (lane & 7) ^ ((row >> 1) & 7);
+            w_src[h][j] = W + (long)min(((p.dbg & 64) ? 0 : n0) + row, p.N - 1) * p.ldw + c * 8;
+        }
+    const bool no_dma = p.dbg & 1, no_mfma = p.dbg & 2, no_rd = p.dbg & 32;
+    auto issue_a = [&](int h, int kt) {
+        if (no_dma) return;
+        char* base = smem + (kt & 1) * BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(a_src[h][j] + kt * BK), (lds_void*)(base + a_row0[h][j] * RB), 16,
+                                             0, 0);
+    };
+    auto issue_w = [&](int h, int kt) {
+        if (no_dma) return;
+        char* base = smem + (kt & 1) * BUF + A_TILE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(w_src[h][j] + kt * BK), (lds_void*)(base + w_row0[h][j] * RB), 16,
+                                             0, 0);
+    };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + j * 32 + l31] = acc[i][j][r];
-        // same-wave LDS write -> read: DS ops of one wave execute in order; the compiler only
-        // needs to keep them in program order
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-        if (EPI != 0) {
-            // straight-line fast path: all 8 row reads in flight, column constants hoisted
-            float4 v[8];
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-                v[it] = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + 4 * (lane & 15)]);
-            if (n < p.N) {
-                const float4 bs = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
-                float4 gm = make_float4(1, 1, 1, 1);
-                if (EPI == 2) gm = *reinterpret_cast<const float4*>(p.gamma + n);
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int m = m0 + wr * (32 * MT) + i * 32 + it * 4 + (lane >> 4);
-                    if (m < p.M && !(p.dbg & 4)) {
-                        float y0 = v[it].x + bs.x, y1 = v[it].y + bs.y, y2 = v[it].z + bs.z, y3 = v[it].w + bs.w;
-                        if (EPI == 1 || EPI == 3) {
-                            if (EPI == 3) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
-                            bf16x4 hb;
-                            hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
-                            bf16x4* dst = reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)m * p.ldo + n);
-                            if (p.dbg & 8) __builtin_nontemporal_store(hb, dst); else *dst = hb;
-                        } else {
-                            const float4 r = *reinterpret_cast<const float4*>((const float*)p.resid + (long)m * p.ldr + n);
-                            f32x4 ov = {r.x + gm.x * y0, r.y + gm.y * y1, r.z + gm.z * y2, r.w + gm.w * y3};
-                            f32x4* dst = reinterpret_cast<f32x4*>((float*)p.out + (long)m * p.ldo + n);
-                            if (p.dbg & 8) __builtin_nontemporal_store(ov, dst); else *dst = ov;
-                        }
-                    }
-                }
-            }
-        } else {
-#pragma unroll 1
-            for (int it = 0; it < 8; ++it) {
-                const int row_l = it * 4 + (lane >> 4);
-                const int m = m0 + wr * (32 * MT) + i * 32 + row_l;
-                if (m >= p.M || n >= p.N) continue;
-                const float4 v = *reinterpret_cast<const float4*>(&stg[row_l * 64 + 4 * (lane & 15)]);
-                const RowMap rm = row_map(p, m);
-                if (p.vec4) {
-                    store_four(p, rm, n, v);
-                } else {
-                    store_one(p, rm, n, v.x);
-                    if (n + 1 < p.N) store_one(p, rm, n + 1, v.y);
-                    if (n + 2 < p.N) store_one(p, rm, n + 2, v.z);
-                    if (n + 3 < p.N) store_one(p, rm, n + 3, v.w);
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: all of K-tile 0, then the two quarters of K-tile 1 that the loop does not issue
+    issue_a(0, 0); issue_w(0, 0); issue_w(1, 0); issue_a(1, 0);
+    if (nkt > 1) {
+        issue_a(0, 1); issue_w(1, 1);
+        SKIMI_VMCNT(4);
+    } else {
+        SKIMI_VMCNT(0);
     }
+    SKIMI_BAR();
+    if (wr == 1) SKIMI_BAR();   // wave row 1 runs one barrier behind wave row 0
+
+    bf16x8 af[2][4], wf[2][4];   // A: [row block within the quadrant][k-step]; W: [jh][k-step]
+    if (no_rd) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) af[i][s] = wf[i][s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char* ab = smem + (kt & 1) * BUF;
+        const char* wb = ab + A_TILE;
+        auto read_a = [&](int ih) {
+            if (no_rd) return;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int row = wr * 128 + (2 * ih + i) * 32 + l31;
+                    af[i][s] = *reinterpret_cast<const bf16x8*>(ab + row * RB + (((2 * s + lh) ^ ((row >> 1) & 7)) << 4));
+                }
+        };
+        auto read_w = [&](int jh) {
+            if (no_rd) return;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int row = wc * 64 + jh * 32 + l31;
+                wf[jh][s] = *reinterpret_cast<const bf16x8*>(wb + row * RB + (((2 * s + lh) ^ ((row >> 1) & 7)) << 4));
+            }
+        };
+#define SKIMI_QUADRANT(IH, JH)                                                                                  \
+    do {                                                                                                         \
+        SKIMI_BAR();                                                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        if (!no_mfma) _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                          \
+            acc[2 * IH][JH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s], wf[JH][s], acc[2 * IH][JH], 0, 0, 0); \
+            acc[2 * IH + 1][JH] =                                                                                \
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s], wf[JH][s], acc[2 * IH + 1][JH], 0, 0, 0);      \
+        }                                                                                                        \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+        SKIMI_BAR();                                                                                             \
+    } while (0)
+
+        // P1
+        read_w(0);
+        read_a(0);
+        if (kt + 1 < nkt) issue_a(1, kt + 1);
+        SKIMI_QUADRANT(0, 0);
+        // P2
+        read_w(1);
+        if (kt + 1 < nkt) issue_w(0, kt + 1);
+        SKIMI_QUADRANT(0, 1);
+        // P3
+        read_a(1);
+        if (kt + 2 < nkt) issue_a(0, kt + 2);
+        SKIMI_QUADRANT(1, 1);
+        // P4
+        if (kt + 2 < nkt) {
+            issue_w(1, kt + 2);
+            SKIMI_VMCNT(4);
+        } else {
+            SKIMI_VMCNT(0);
+        }
+        SKIMI_QUADRANT(1, 0);
+#undef SKIMI_QUADRANT
+    }
+    if (wr == 0) SKIMI_BAR();   // re-align the two wave rows: nobody reads operand tiles any more
+
+    epilogue256<MT, EPI>(p, acc, smem, wave, lane, wr, wc, m0, n0);
 }
+
 
 // which compile-time epilogue serves this launch (0 = generic)
 static int epi_kind(const GemmArgs& a) {
@@ -240,6 +471,27 @@ static int launch256(GemmArgs& a, hipStream_t st) {
     return SKIMI_OK;
 }
 
+template <int EPI>
+static int launch256pp(GemmArgs& a, hipStream_t st) {
+    constexpr size_t lds = 2ull * (256 + 256) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(gemm256pp) failed: %s", hipGetErrorString(e));
+            return SKIMI_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    a.ntm = (int)cdiv(a.M, 256);
+    a.ntn = (int)cdiv(a.N, 256);
+    a.splitk = 1;
+    hipLaunchKernelGGL((gemm256pp_kernel<EPI>), dim3(a.ntm * a.ntn), dim3(512), lds, st, a);
+    SKIMI_LAUNCH_CHECK();
+    return SKIMI_OK;
+}
+
 // pick the tile height (192 or 256 rows) that wastes the fewest CU-rounds for this shape:
 // one workgroup per CU, so time ~ ceil(tiles / 256) * (rows per tile)
 int gemm256_launch(GemmArgs& a, hipStream_t st) {
@@ -250,15 +502,24 @@ int gemm256_launch(GemmArgs& a, hipStream_t st) {
         return (double)cdiv(tiles, 256) * bm;
     };
     const int epi = epi_kind(a);
+    // 192-row tiles (two-phase loop) when they waste fewer CU-rounds, else 256-row tiles on the
+    // ping-pong loop; SKIMI_GEMM256_PP=0 forces the two-phase loop (A/B timing)
+    static const int use_pp = getenv("SKIMI_GEMM256_PP") ? atoi(getenv("SKIMI_GEMM256_PP")) : 1;
     if (cost(192) < cost(256)) {
         if (epi == 1) return launch256<3, 1>(a, st);
-        if (epi == 3) return launch256<3, 3>(a, st);
         if (epi == 2) return launch256<3, 2>(a, st);
+        if (epi == 3) return launch256<3, 3>(a, st);
         return launch256<3, 0>(a, st);
     }
+    if (use_pp) {
+        if (epi == 1) return launch256pp<1>(a, st);
+        if (epi == 2) return launch256pp<2>(a, st);
+        if (epi == 3) return launch256pp<3>(a, st);
+        return launch256pp<0>(a, st);
+    }
     if (epi == 1) return launch256<4, 1>(a, st);
-    if (epi == 3) return launch256<4, 3>(a, st);
     if (epi == 2) return launch256<4, 2>(a, st);
+    if (epi == 3) return launch256<4, 3>(a, st);
     return launch256<4, 0>(a, st);
 }
 

@@ -208,9 +208,13 @@ def test_attention_bf16_online_softmax_rescale():
     assert (out.float().cpu() - ref).abs().max().item() < 3e-2
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 512, 64), (2100, 768, 1024), (10992, 1024, 4096)])
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 64), (4096, 1024, 128), (4300, 768, 192), (2100, 768, 1024),
+                                   (10992, 1024, 4096),
+                                   # 256 tiles of 256 rows beat 192-row tiles -> ping-pong main loop
+                                   (16384, 1024, 64), (16384, 1024, 128), (16300, 1000, 192), (16384, 1024, 1024)])
 def test_gemm256_lds_dma_path(M, N, K):
-    """bf16 x bf16 plain-row shapes with M >= 2048 take the 256x256 LDS-DMA kernel."""
+    """bf16 x bf16 plain-row shapes with M >= 2048 take the 256x256 LDS-DMA kernels (two-phase
+    192-row tiles or the ping-pong 256-row loop, whichever wastes fewer CU rounds)."""
     a = (_rand(M, K, seed=70)).to(torch.bfloat16)
     w = (_rand(N, K, seed=71, scale=1 / math.sqrt(K))).to(torch.bfloat16)
     b, g, r = _rand(N, seed=72), _rand(N, seed=73), _rand(M, N, seed=74)
