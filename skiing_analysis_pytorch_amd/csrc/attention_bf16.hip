@@ -11,6 +11,8 @@
 //                          row-major [key][d] tile), B = P: the S^T accumulator converted to bf16
 //                          in place (k order inside a step: key = 16s + 8(j>>2) + 4h + (j&3)).
 // blockIdx -> (batch, head, q-block) is XCD-contiguous so one XCD's L2 holds a head's K/V.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -28,6 +30,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& p, int s) {
     return r;
 }
 
+template <int dbg>   // dbg != 0: timing ablations only (SKIMI_ATTN_ABL), results are wrong
 __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const AttnArgs a, int nqb) {
     constexpr int KV = 64;                 // keys per tile
     constexpr int TILE = KV * 64 * 2;      // bytes of one K (or V) tile
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const AttnArgs a, int
             const int row = t * 32 + l31;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf =
+                const bf16x8 kf = (dbg & 1) ? qf[ks] :
                     *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
                 // the first k-step takes the constant 0 as C (inline operand: no 16-register clear)
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : s[t], 0, 0, 0);
@@ -159,8 +162,10 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const AttnArgs a, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             // one v_fma per score (the build runs with -ffp-contract=off, so spell the fma out)
-            s[0][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][r], c2, nmb));
-            s[1][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][r], c2, nmb));
+            if (!(dbg & 4)) {
+                s[0][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][r], c2, nmb));
+                s[1][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][r], c2, nmb));
+            }
         }
 
         // ---- O^T += V^T P^T ----
@@ -169,13 +174,14 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const AttnArgs a, int
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 pf = pack8(s[t], ks);
-                lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+                if (!(dbg & 8)) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     // tr-read block: rows key0 + q (q = (lane&15)>>2), cols dcol0 + 4p (p = lane&3)
                     const int q4 = (lane & 15) >> 2, p4 = lane & 3;
                     const int dcol = dt * 32 + 16 * ((lane >> 4) & 1) + 4 * p4;   // first of 4 d columns
-                    bf16x8 vf;
+                    bf16x8 vf = qf[0];
+                    if (!(dbg & 2))
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         const int row = t * 32 + 16 * ks + 8 * half + 4 * lh + q4;
@@ -224,7 +230,18 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
     SKIMI_CHECK_ARG(nblk < (1l << 31), "skimi_attention: grid too large");
     const bool prof = prof_armed(PROF_ATTN_BF16, a.seq_k);
     if (prof) prof_before(st);
-    hipLaunchKernelGGL(attn_bf16_kernel, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb);
+    static const int dbg = getenv("SKIMI_ATTN_ABL") ? atoi(getenv("SKIMI_ATTN_ABL")) : 0;
+    static const int q64 = getenv("SKIMI_ATTN_Q64") ? atoi(getenv("SKIMI_ATTN_Q64")) : 1;
+    if (q64) {
+        attention_q64_dispatch(a, st);
+    } else
+    switch (dbg) {
+#define SKIMI_ABL_CASE(D) case D: hipLaunchKernelGGL(attn_bf16_kernel<D>, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb); break;
+        SKIMI_ABL_CASE(1) SKIMI_ABL_CASE(2) SKIMI_ABL_CASE(3) SKIMI_ABL_CASE(4) SKIMI_ABL_CASE(8) SKIMI_ABL_CASE(12)
+        SKIMI_ABL_CASE(15)
+#undef SKIMI_ABL_CASE
+        default: hipLaunchKernelGGL(attn_bf16_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb);
+    }
     if (prof) {
         const double bh = (double)a.batch * a.heads;
         prof_after(st, 4.0 * bh * a.seq_q * (double)a.seq_k * 64.0,
