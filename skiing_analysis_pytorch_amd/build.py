@@ -32,6 +32,18 @@ CXXFLAGS = [
 ]
 
 
+# Per-file extras.  The attention kernels must not get packed-fp32 VALU ops (v_pk_fma_f32,
+# v_pk_add_f32, v_pk_mul_f32 -- what the SLP vectorizer makes of adjacent scalar float ops): on
+# gfx950 VOP3P instructions do not co-issue with an MFMA in flight (tools/coissue.hip: +5 cycles
+# each on top of the MFMA, where v_fma_f32 / v_add_f32 / v_exp_f32 / v_max3_f32 hide completely),
+# and the softmax VALU stream is what the attention MFMAs have to overlap with.
+EXTRA_FLAGS = {
+    "attention_bf16.hip": ["-fno-slp-vectorize"],
+    "attention_q64.hip": ["-fno-slp-vectorize"],
+    "attention_pipe.hip": ["-fno-slp-vectorize"],
+}
+
+
 def _digest(paths) -> str:
     h = hashlib.sha256()
     for p in sorted(paths):
@@ -56,6 +68,8 @@ def build(verbose: bool = False, jobs: int = 4) -> Path:
     objs, todo = [], []
     for src in sources():
         tag = _digest([src]) + "_" + hdr_digest
+        if src.name in EXTRA_FLAGS:
+            tag += "_" + hashlib.sha256(" ".join(EXTRA_FLAGS[src.name]).encode()).hexdigest()[:6]
         obj = OBJ / f"{src.stem}.{tag}.o"
         objs.append(obj)
         if not obj.exists():
@@ -65,7 +79,7 @@ def build(verbose: bool = False, jobs: int = 4) -> Path:
 
     def compile_one(job):
         src, obj = job
-        cmd = [HIPCC, *CXXFLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [HIPCC, *CXXFLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

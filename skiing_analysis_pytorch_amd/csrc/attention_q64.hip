@@ -103,10 +103,9 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qi][dt][r] = 0.f;
-    f32x2 lsum[2] = {{0.f, 0.f}, {0.f, 0.f}};   // this lane's partial row sums (its 32 of every 64 keys)
+    float lsum[2] = {0.f, 0.f};   // this lane's partial row sums (its 32 of every 64 keys)
     float m[2] = {-INFINITY, -INFINITY};
     const float c2 = a.scale * 1.44269504088896340736f;   // softmax scale folded into exp2
-    const f32x2 c22 = {c2, c2};
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     issue(0, 0);
@@ -200,21 +199,23 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
                 lsum[qi] *= alpha;
                 m[qi] = mnew;
             }
-            const f32x2 nmb2 = {nmb, nmb};
+            // scalar VALU on purpose: packed-fp32 (VOP3P) ops do not co-issue with MFMAs (build.py)
+            float l0 = 0.f, l1 = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    f32x2 v = {s[qi][t][r], s[qi][t][r + 1]};
-                    v = __builtin_elementwise_fma(v, c22, nmb2);
+                    float v0 = __builtin_fmaf(s[qi][t][r], c2, nmb), v1 = __builtin_fmaf(s[qi][t][r + 1], c2, nmb);
                     if (!(dbg & 2)) {
-                        v[0] = __builtin_amdgcn_exp2f(v[0]);
-                        v[1] = __builtin_amdgcn_exp2f(v[1]);
+                        v0 = __builtin_amdgcn_exp2f(v0);
+                        v1 = __builtin_amdgcn_exp2f(v1);
                     }
-                    lsum[qi] += v;
-                    s[qi][t][r] = v[0];
-                    s[qi][t][r + 1] = v[1];
+                    l0 += v0;
+                    l1 += v1;
+                    s[qi][t][r] = v0;
+                    s[qi][t][r + 1] = v1;
                 }
+            lsum[qi] += l0 + l1;
 
             // ---- O^T += V^T P^T (P = the S^T accumulator as bf16, k order of attention_bf16.hip) ----
 #pragma unroll
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
 
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-        const float inv = 1.f / xhalf_sum(lsum[qi][0] + lsum[qi][1]);
+        const float inv = 1.f / xhalf_sum(lsum[qi]);
         const int q = q0 + qi * 32 + l31;
         if (q < a.seq_q) {
             unsigned short* op = O + (long)q * a.o_row;

@@ -31,7 +31,8 @@ struct AttnArgs {
 };
 int attention_f32_launch(const AttnArgs& a, hipStream_t st);
 int attention_bf16_launch(const AttnArgs& a, hipStream_t st);
-void attention_q64_dispatch(const AttnArgs& a, hipStream_t st);   // attention_q64.hip: 64 queries per wave
+void attention_q64_dispatch(const AttnArgs& a, hipStream_t st);    // attention_q64.hip: 64 queries per wave
+void attention_pipe_dispatch(const AttnArgs& a, hipStream_t st);   // attention_pipe.hip: skewed half-step pipeline
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
                      hipStream_t st);
 
