@@ -144,7 +144,7 @@ def main():
         avg_s = ms.value * 1e-3 / n.value
         flops_per_launch = fl.value / n.value
         ach = flops_per_launch / avg_s / 1e12
-        line["roofline"] = {"kernel": "attn_bf16_kernel (global attention, seq 10992, 16 heads x 64)",
+        line["roofline"] = {"kernel": "attn_q64_kernel (global attention, seq 10992, 16 heads x 64)",
                             "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
                             "avg_launch_us": avg_s * 1e6, "launches": int(n.value),

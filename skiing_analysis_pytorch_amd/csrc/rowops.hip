@@ -283,11 +283,120 @@ __global__ __launch_bounds__(256) void qknorm_rope_vec_kernel(T* __restrict__ qk
     }
 }
 
+// Second-generation bf16 q/k-norm + RoPE (the aggregator's shape: head_dim 64, affine LayerNorm, 2-D
+// RoPE).  The first vector kernel re-read 128 B of LayerNorm parameters and 64 B of RoPE table per
+// 16-B vector through the L1 (9x the payload) and crossed lanes through ds_bpermute; here
+//   * a thread keeps its 8 features' q and k LayerNorm parameters in registers for its whole
+//     grid-stride loop (the feature slot of a thread never changes);
+//   * the two RoPE tables ([npos][16] cos / sin, a few KiB) are staged in LDS once per workgroup;
+//   * the 8-lane reductions and the RoPE partner exchange are DPP moves (quad_perm / half-row
+//     mirror), no LDS traffic;
+//   * q and k rows of one (token, head) are processed together: two independent 16-B loads in flight.
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float dpp_mirror8(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+}
+__device__ __forceinline__ float sum8(float s) {
+    s += dpp_xor1(s);
+    s += dpp_xor2(s);
+    s += dpp_mirror8(s);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void qknorm_rope_bf16_kernel(unsigned short* __restrict__ qkv, long tokens, int heads,
+                                                               const float* __restrict__ qn_w,
+                                                               const float* __restrict__ qn_b,
+                                                               const float* __restrict__ kn_w,
+                                                               const float* __restrict__ kn_b, float eps,
+                                                               const int* __restrict__ pos,
+                                                               const float* __restrict__ rcos,
+                                                               const float* __restrict__ rsin, int npos) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];   // [2][npos][16]
+    for (int i = threadIdx.x; i < npos * 16; i += 256) {
+        tab[i] = rcos[i];
+        tab[npos * 16 + i] = rsin[i];
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7;                  // features 8*sub .. 8*sub+7
+    float w[2][8], b[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        w[0][j] = qn_w[8 * sub + j]; b[0][j] = qn_b ? qn_b[8 * sub + j] : 0.f;
+        w[1][j] = kn_w[8 * sub + j]; b[1][j] = kn_b ? kn_b[8 * sub + j] : 0.f;
+    }
+    const int sect = sub >> 2;                        // features 0-31 rotate by y, 32-63 by x
+    const int d0 = (8 * sub) & 15;                    // table column of the first feature
+    const bool lower = ((8 * sub) & 31) < 16;         // partner is d + 16 (else d - 16)
+    const long total = tokens * heads;
+    const long step = (long)gridDim.x * 32;
+    // every lane runs the same trip count (DPP needs its 8-lane group complete): clamp, mask the store
+    const long trips = (total + step - 1) / step;
+    long idx = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    for (long it = 0; it < trips; ++it, idx += step) {
+        const bool live = idx < total;
+        const long ii = live ? idx : total - 1;
+        const long tok = ii / heads;
+        const int h = (int)(ii - tok * heads);
+        unsigned short* pq = qkv + ((tok * 3) * heads + h) * 64 + 8 * sub;
+        unsigned short* pk = pq + (long)heads * 64;
+        const bf16x8 raw[2] = {*reinterpret_cast<const bf16x8*>(pq), *reinterpret_cast<const bf16x8*>(pk)};
+        int pp = pos[tok * 2 + sect];
+        pp = min(max(pp, 0), npos - 1);
+        const float4 c0 = *reinterpret_cast<const float4*>(&tab[pp * 16 + d0]);
+        const float4 c1 = *reinterpret_cast<const float4*>(&tab[pp * 16 + d0 + 4]);
+        const float4 s0 = *reinterpret_cast<const float4*>(&tab[npos * 16 + pp * 16 + d0]);
+        const float4 s1 = *reinterpret_cast<const float4*>(&tab[npos * 16 + pp * 16 + d0 + 4]);
+        const float ct[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const float st[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        bf16x8 outv[2];
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = bf2f((unsigned short)raw[z][j]);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += t[j];
+            const float mean = sum8(s) * (1.f / 64.f);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { t[j] -= mean; q += t[j] * t[j]; }
+            const float rstd = rsqrtf(sum8(q) * (1.f / 64.f) + eps);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = t[j] * rstd * w[z][j] + b[z][j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float other = dpp_xor2(t[j]);   // feature d +- 16 lives two lanes away
+                const float rot = lower ? -other : other;
+                outv[z][j] = (short)f2bf(t[j] * ct[j] + rot * st[j]);
+            }
+        }
+        if (live) {
+            *reinterpret_cast<bf16x8*>(pq) = outv[0];
+            *reinterpret_cast<bf16x8*>(pk) = outv[1];
+        }
+    }
+}
+
 int qknorm_rope_launch(void* qkv, int dtype, int64_t tokens, int heads, const float* qn_w, const float* qn_b,
                        const float* kn_w, const float* kn_b, float eps, const int32_t* pos,
                        const float* rope_cos, const float* rope_sin, int rope_npos, hipStream_t st) {
     SKIMI_CHECK_ARG(qkv && tokens > 0 && heads > 0, "skimi_qknorm_rope: bad arguments");
     SKIMI_CHECK_ARG(pos == nullptr || (rope_cos && rope_sin && rope_npos > 0), "skimi_qknorm_rope: pos without tables");
+    if (((uintptr_t)qkv & 15) == 0 && dtype == SKIMI_BF16 && qn_w && kn_w && pos && rope_npos * 128 <= 48 * 1024) {
+        const long total = tokens * heads;
+        const unsigned blocks = (unsigned)std::min<long>(cdiv(total, 32), 256 * 8);
+        hipLaunchKernelGGL(qknorm_rope_bf16_kernel, dim3(blocks), dim3(256), (size_t)rope_npos * 128, st,
+                           (unsigned short*)qkv, (long)tokens, heads, qn_w, qn_b, kn_w, kn_b, eps, pos, rope_cos, rope_sin,
+                           rope_npos);
+        SKIMI_LAUNCH_CHECK();
+        return SKIMI_OK;
+    }
     if (((uintptr_t)qkv & 15) == 0) {
         const long threads = tokens * 2 * heads * 8;
         dim3 g((unsigned)cdiv(threads, 256)), blk(256);

@@ -499,15 +499,18 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
             d2.resid = cur; d2.ldr = feat; d2.resid_dtype = adt;
             c.gemm(d2);
         }
-        // bilinear (align_corners) to the next level's size (x2 for refinenet1), then out_conv 1x1
+        // dpt_head.py:447-455 upsamples (bilinear, align_corners) to the next level's size (x2 for
+        // refinenet1) and then applies the 1x1 out_conv.  Both are linear maps over different axes
+        // (space / channels) and the interpolation weights sum to 1, so they commute exactly, bias
+        // included; the 1x1 conv runs here on the 4x smaller map, fp32 rounding order aside.
         const int h1 = r > 0 ? hh[r - 1] : 2 * h0, w1 = r > 0 ? ww[r - 1] : 2 * w0;
-        void* up = c.ar.alloc((size_t)F * h1 * w1 * feat * es);
-        if (!c.rc && !c.dry()) c.rc = bilinear_ac_launch(u, up, adt, F, h0, w0, h1, w1, feat, c.st);
-        void* o = c.ar.alloc((size_t)F * h1 * w1 * feat * es);
+        void* olow = c.ar.alloc(bytes);
         {
-            auto d = c.desc(f.out_conv, up, adt, feat, F * h1 * w1, o, adt, feat);
+            auto d = c.desc(f.out_conv, u, adt, feat, M, olow, adt, feat);
             c.gemm(d);
         }
+        void* o = c.ar.alloc((size_t)F * h1 * w1 * feat * es);
+        if (!c.rc && !c.dry()) c.rc = bilinear_ac_launch(olow, o, adt, F, h0, w0, h1, w1, feat, c.st);
         prev = o;
         hh[r] = h1; ww[r] = w1;   // resolution of `prev`
     }
@@ -521,11 +524,12 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
     }
     const int Ho = ph * c.h->cfg.patch_size / w.down_ratio, Wo = pw * c.h->cfg.patch_size / w.down_ratio;
     void* c1u = c.ar.alloc((size_t)F * Ho * Wo * f2 * es);
-    if (!c.rc && !c.dry()) c.rc = bilinear_ac_launch(c1, c1u, adt, F, h1, w1, Ho, Wo, f2, c.st);
-    if (w.pos_embed && !c.rc && !c.dry()) {
-        const UvTab* t = find_uv(c.h, Wo, Ho, f2);
-        if (!t) { set_error("uv table missing"); c.rc = SKIMI_ERR_STATE; }
-        else c.rc = add_uv_pos_launch(c1u, adt, t->tx, t->ty, F, Ho, Wo, f2, c.st);
+    {
+        // upsample to the output size with the UV positional embedding added in the same pass
+        const UvTab* t = w.pos_embed ? find_uv(c.h, Wo, Ho, f2) : nullptr;
+        if (w.pos_embed && !t && !c.rc && !c.dry()) { set_error("uv table missing"); c.rc = SKIMI_ERR_STATE; }
+        if (!c.rc && !c.dry())
+            c.rc = bilinear_ac_launch(c1, c1u, adt, F, h1, w1, Ho, Wo, f2, c.st, t ? t->tx : nullptr, t ? t->ty : nullptr);
     }
     if (w.feature_only) return c1u;   // caller releases the arena
     void* c2 = c.ar.alloc((size_t)F * Ho * Wo * 32 * es);

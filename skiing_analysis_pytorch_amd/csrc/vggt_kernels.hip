@@ -88,7 +88,9 @@ int special_tokens_launch(float* x, const float* table, int F, int S, int P, int
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ in, T* __restrict__ out, int N,
-                                                          int h, int w, int H, int W, int C) {
+                                                          int h, int w, int H, int W, int C,
+                                                          const float* __restrict__ tabx,
+                                                          const float* __restrict__ taby) {
     const int C4 = C / 4;
     const long total = (long)N * H * W * C4;
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
@@ -123,6 +125,13 @@ __global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             r[k] = ly0 * (lx0 * p00[k] + lx1 * p01[k]) + ly1 * (lx0 * p10[k] + lx1 * p11[k]);
+        if (tabx != nullptr) {
+            // fused UV positional embedding of the upsampled map (add_uv_pos_kernel below, same add)
+            const int half = C / 2, c = c4 * 4;
+            const float4 e = *reinterpret_cast<const float4*>(c < half ? tabx + (long)X * half + c
+                                                                        : taby + (long)Y * half + (c - half));
+            r[0] += e.x; r[1] += e.y; r[2] += e.z; r[3] += e.w;
+        }
         T* o = out + ((n * H + Y) * (long)W + X) * C + c4 * 4;
         if (sizeof(T) == 4) {
             *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
@@ -136,15 +145,16 @@ __global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ 
 }
 
 int bilinear_ac_launch(const void* in, void* out, int dtype, int N, int h, int w, int H, int W, int C,
-                       hipStream_t st) {
+                       hipStream_t st, const float* tabx, const float* taby) {
     SKIMI_CHECK_ARG(C % 4 == 0, "bilinear resize needs C %% 4 == 0");
+    SKIMI_CHECK_ARG(tabx == nullptr || (taby != nullptr && C % 8 == 0), "fused uv pos embed needs both tables, C %% 8 == 0");
     const long total = (long)N * H * W * (C / 4);
     if (dtype == SKIMI_F32)
         hipLaunchKernelGGL(bilinear_ac_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st,
-                           (const float*)in, (float*)out, N, h, w, H, W, C);
+                           (const float*)in, (float*)out, N, h, w, H, W, C, tabx, taby);
     else
         hipLaunchKernelGGL(bilinear_ac_kernel<unsigned short>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st,
-                           (const unsigned short*)in, (unsigned short*)out, N, h, w, H, W, C);
+                           (const unsigned short*)in, (unsigned short*)out, N, h, w, H, W, C, tabx, taby);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }

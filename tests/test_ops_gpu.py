@@ -150,9 +150,9 @@ def _rope_ref(t, pos, cos_t, sin_t):
     return torch.cat((one(v, pos[..., 0]), one(h, pos[..., 1])), -1)
 
 
+@pytest.mark.parametrize("tokens,heads", [(200, 4), (201, 3), (5000, 16)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_qknorm_rope(dtype):
-    tokens, heads = 200, 4
+def test_qknorm_rope(dtype, tokens, heads):
     qkv = _rand(tokens, 3 * heads * 64, seed=50)
     qw, qb, kw, kb = (_rand(64, seed=51 + i) for i in range(4))
     pos = torch.stack([torch.arange(tokens) % 38, (torch.arange(tokens) * 7) % 38], -1).to(torch.int32)
@@ -166,8 +166,10 @@ def test_qknorm_rope(dtype):
     ref = torch.stack([q, k, x[:, 2]], 1).reshape(tokens, -1)
     buf = qkv.to(dtype).clone()
     ops.qknorm_rope_(buf, heads, qw, qb, kw, kb, 1e-5, pos.to(DEV), cos_t.to(DEV), sin_t.to(DEV))
-    tol = 2e-5 if dtype == torch.float32 else 3e-2
-    assert (buf.float().cpu() - ref).abs().max().item() < tol
+    # fp32: absolute; bf16: the stored result is rounded to 8 significant bits (half an ulp = 2^-9 relative)
+    err = (buf.float().cpu() - ref).abs()
+    bound = 2e-5 if dtype == torch.float32 else (5e-3 + 4e-3 * ref.abs())
+    assert bool((err <= bound).all())
     # v untouched, bit for bit
     assert torch.equal(buf.reshape(tokens, 3, -1)[:, 2], qkv.to(dtype).reshape(tokens, 3, -1)[:, 2])
 
