@@ -146,7 +146,7 @@ def main():
         ach = flops_per_launch / avg_s / 1e12
         line["roofline"] = {"kernel": "attn_q64_kernel (global attention, seq 10992, 16 heads x 64)",
                             "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                            "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(B),
                             "avg_launch_us": avg_s * 1e6, "launches": int(n.value),
                             "flops_per_launch": flops_per_launch}
     if rank == 0 and cpu_sd is not None:
@@ -155,6 +155,18 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def pmc_traffic(time_steps):
+    """HBM bytes per global-attention launch from the committed rocprofv3 PMC passes
+    (profiles/r01_attn_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE), or None when the
+    profile was taken at another launch shape."""
+    f = Path(__file__).resolve().parent / "profiles" / "r01_attn_traffic.json"
+    try:
+        d = json.loads(f.read_text())
+    except (OSError, ValueError):
+        return None
+    return d["hbm_bytes_per_launch"] if d.get("time_steps") == time_steps else None
 
 
 def cpu_baseline(cpu_sd, cfg, views, model, dev):
