@@ -252,6 +252,21 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs a, int
 #define SKIMI_QK(S, QI)                                                                                          \
     if (!(dbg & 1)) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) S =                                                          \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[QI][ks], ks == 0 ? zero16 : S, 0, 0, 0)
+// the same product in two halves (k-steps 0,1 / 2,3), so that a max region carries 2 MFMAs and an
+// exp region 6: one MFMA per ~30 cycles of VALU issue everywhere (a wave issues in order; a run of
+// MFMAs blocks its own VALU stream behind the busy matrix pipe and vice versa)
+#define SKIMI_QK_A(S, QI)                                                                                        \
+    if (!(dbg & 1)) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) S =                                                          \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[QI][ks], ks == 0 ? zero16 : S, 0, 0, 0)
+#define SKIMI_QK_B(S, QI)                                                                                        \
+    if (!(dbg & 1)) _Pragma("unroll") for (int ks = 2; ks < 4; ++ks) S =                                                          \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[QI][ks], S, 0, 0, 0)
+// ask the scheduler for 6 x (1 MFMA, then NV VALU) in the current region
+#define SKIMI_INTERLEAVE6(NV)                                                                                    \
+    _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                                                      \
+    }
 #define SKIMI_PV(QI)                                                                                             \
     if (!(dbg & 1)) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int dt = 0; dt < 2; ++dt) o[QI][dt] = \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks][dt], pf[QI][ks], o[QI][dt], 0, 0, 0)
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs a, int
             const bool more = hh == 0 || !LAST;   // compile-time after unrolling
             // ---------------- X(j) ----------------
             if (LAST) mask(s0, j);
-            SKIMI_QK(s1, 1);                       // K(j) still in kf
+            SKIMI_QK_A(s1, 1);                     // K(j) in kf
             float nmb0 = sm_head(s0, 0);
             bf16x8 kn[4];
             if (more) {
@@ -295,11 +310,13 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs a, int
                 const unsigned kb = lds0 + (hh == 0 ? slot + 4096u : nslot);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) ka[ks] = kb + (unsigned)koff[ks];
-                if (!(dbg & 8)) SKIMI_KREAD(kn, ka, nmb0);         // K(j+1)
+                if (!(dbg & 8)) SKIMI_KREAD(kn, ka, nmb0);         // K(j+1) into its own registers
                 else { kn[0] = kf[0]; kn[1] = kf[1]; kn[2] = kf[2]; kn[3] = kf[3]; }
             }
+            SKIMI_QK_B(s1, 1);
             SKIMI_PV(1);                           // O1 += V(j-1)^T P1(j-1)
             sm_body(s0, 0, nmb0);
+            SKIMI_INTERLEAVE6(11);
             if (!(dbg & 8)) SKIMI_TR8(h, voff[0] + slot + hh * 4096, voff[1] + slot + hh * 4096, pf[0][1]);   // V(j)
             // ---------------- Y(j) ----------------
             if (LAST) mask(s1, j);
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs a, int
                 if (!(dbg & 8)) SKIMI_KWAIT(kn);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) kf[ks] = kn[ks];
-                SKIMI_QK(s0, 0);                   // S0(j+1) from K(j+1)
+                SKIMI_QK_A(s0, 0);                 // S0(j+1) from K(j+1)
             }
             float nmb1 = sm_head(s1, 1);
             if (!(dbg & 8)) SKIMI_TR8_WAIT(h, nmb1);
@@ -320,14 +337,19 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs a, int
                         vf[ks][dt][e] = h[4 * ks + 2 * dt][e];
                         vf[ks][dt][4 + e] = h[4 * ks + 2 * dt + 1][e];
                     }
+            if (more) SKIMI_QK_B(s0, 0);
             SKIMI_PV(0);                           // O0 += V(j)^T P0(j)
             sm_body(s1, 1, nmb1);
+            SKIMI_INTERLEAVE6(11);
         }
     };
     for (int kt = 0; kt + 1 < nkt; ++kt) tile(kt, std::false_type{});
     tile(nkt - 1, std::true_type{});
     SKIMI_PV(1);   // O1 += V(J-1)^T P1(J-1)
 #undef SKIMI_QK
+#undef SKIMI_QK_A
+#undef SKIMI_QK_B
+#undef SKIMI_INTERLEAVE6
 #undef SKIMI_PV
 
 #pragma unroll
