@@ -149,12 +149,71 @@ def main():
                             "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(B),
                             "avg_launch_us": avg_s * 1e6, "launches": int(n.value),
                             "flops_per_launch": flops_per_launch}
+    if rank == 0:
+        line["vp3d"] = vp3d_leg(dev, cpu=not args.no_cpu_baseline)
     if rank == 0 and cpu_sd is not None:
         line["cpu_baseline"], line["parity_vs_cpu_oracle"] = cpu_baseline(cpu_sd, cfg, args.cpu_views, model, dev)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def cpu_threads():
+    """Threads for the CPU legs: this process's CPU share (16 on a one-GPU box), set in torch."""
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, int(os.environ.get("SKIMI_CPU_THREADS", "16"))))
+    torch.set_num_threads(threads)
+    return threads
+
+
+def vp3d_leg(dev, cpu=True):
+    """Second leg of the path (BASELINE configs[0]): the VideoPose3D TemporalModel lifter, receptive
+    field 27, 17 COCO joints, 243-frame clips of synthetic 2D keypoints, fp32-accurate mode.  Not part
+    of `value`; reported beside it: HIP-event time per call, clips/s, and the achieved fraction of the
+    HBM roofline on the algorithmic bytes (weights once per call + activations once per layer)."""
+    from skiing_analysis_pytorch_amd import vp3d, weights as W
+    from skiing_analysis_pytorch_amd._lib import PREC_BF16X3
+    fw = [3, 3, 3]
+    sd = W.make_vp3d_state_dict(seed=0, filter_widths=fw)
+    m = vp3d.TemporalModel(17, 2, 17, fw, prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    wbytes = sum(v.numel() * 4 for k, v in sd.items() if k.endswith("weight") and v.dim() == 3)
+    res = {"model": "TemporalModel RF 27, 1024 channels, bf16x3 (fp32-accurate), 243-frame clips", "hbm_peak_GBps": 8000.0}
+    for B in (1, 64):
+        x = torch.randn(B, 243, 17, 2, device=dev)
+        out = torch.empty(B, 217, 17, 3, device=dev)
+        for _ in range(3):
+            m(x, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 50 if B == 1 else 10
+        e0.record()
+        for _ in range(n):
+            m(x, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / n
+        # activations: fp32 [B*L, 1024] written and read once per conv (10 convs, L shrinking 241 -> 217)
+        act = sum(2 * B * L * 1024 * 4 for L in (241, 235, 235, 217, 217)) * 2
+        res[f"clips_{B}"] = {"us_per_call": t * 1e6, "clips_per_s": B / t, "frames_per_s": B * 243 / t,
+                             "algorithmic_GB": (wbytes + act) / 1e9, "achieved_GBps": (wbytes + act) / t / 1e9,
+                             "frac_of_hbm_peak": (wbytes + act) / t / 8e12}
+    if cpu:
+        from oracle import vp3d_oracle   # test infrastructure: the timed CPU baseline only
+        kp = W.make_keypoints_2d(frames=243, seed=1).numpy()
+        threads = cpu_threads()
+        vp3d_oracle.lift_clip(sd, kp, 1920, 1080, fw)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ref = vp3d_oracle.lift_clip(sd, kp, 1920, 1080, fw)
+        tc = (time.perf_counter() - t0) / 3
+        got = vp3d.lift_clip(m, kp, 1920, 1080)
+        res["cpu_oracle"] = {"s_per_clip_with_flip_tta": tc, "cores": threads,
+                             "max_abs_joint_err_vs_hip": float(abs(got - ref).max())}
+    return res
 
 
 def pmc_traffic(time_steps):
@@ -177,12 +236,7 @@ def cpu_baseline(cpu_sd, cfg, views, model, dev):
 
     # cores actually granted to this process (the GPU box gives a 1-GPU job a 16-core share;
     # os.cpu_count() reports the whole host and oversubscribes)
-    try:
-        threads = len(os.sched_getaffinity(0))
-    except AttributeError:
-        threads = os.cpu_count() or 1
-    threads = max(1, min(threads, int(os.environ.get("SKIMI_CPU_THREADS", "16"))))
-    torch.set_num_threads(threads)
+    threads = cpu_threads()
     img = torch.rand((1, views, 3, IMG, IMG), generator=torch.Generator().manual_seed(5))
     d = cfg.to_dict()
     d["enable_track"] = False

@@ -110,10 +110,11 @@ class TemporalModel:
         self._finalized = True
         return self
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        return self.forward(x)
+    def __call__(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        return self.forward(x, out)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """`out` (optional, beyond the reference signature): write the result into a caller buffer."""
         assert len(x.shape) == 4  # model.py:64-66
         assert x.shape[-2] == self.num_joints_in
         assert x.shape[-1] == self.in_features
@@ -122,7 +123,11 @@ class TemporalModel:
         x = x.contiguous().to(torch.float32)
         B, L = x.shape[0], x.shape[1]
         rf = self.receptive_field()
-        out = torch.empty((B, L - rf + 1, self.num_joints_out, 3), dtype=torch.float32, device=x.device)
+        oshape = (B, L - rf + 1, self.num_joints_out, 3)
+        if out is None:
+            out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != oshape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+            raise _lib.SkimiError(f"out must be a contiguous float32 tensor of shape {oshape} on {x.device}")
         need = lib().skimi_vp3d_workspace_bytes(self._h, B, L)
         if need == 0:
             raise _lib.SkimiError(f"input of {L} frames is shorter than the receptive field {rf}")

@@ -63,6 +63,19 @@ def test_vp3d_bf16_mode_tolerance():
     assert rel < 3e-2, rel
 
 
+def test_vp3d_out_buffer_reuse():
+    """`out=` (beyond the reference signature) writes into a caller buffer; shape errors are loud."""
+    fw = [3, 3, 3]
+    m = _model(fw, False, PREC_BF16X3)
+    x = torch.randn(2, 60, 17, 2, device="cuda")
+    out = torch.empty(2, 60 - 26, 17, 3, device="cuda")
+    r = m(x, out=out)
+    assert r.data_ptr() == out.data_ptr()
+    assert (out.cpu() - m(x).cpu()).abs().max().item() < 2e-4   # split-K float atomics: last bits vary
+    with pytest.raises(Exception):
+        m(x, out=torch.empty(2, 10, 17, 3, device="cuda"))
+
+
 def test_vp3d_short_input_rejected():
     from skiing_analysis_pytorch_amd import _lib
 
