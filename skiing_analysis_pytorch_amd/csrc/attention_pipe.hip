@@ -20,13 +20,22 @@
 // the first transposed read after any LDS-DMA issue (it cannot tell the ring slots apart), which
 // would drain the prefetch every tile.
 //
-// STATUS: correct (same tests as the other two kernels) but NOT the default: 2186 us vs 2098 us
-// (attention_q64.hip) on 4 x 10992 keys x 16 heads.  Ablations on this kernel: softmax VALU stream
-// alone 1285 us, MFMA + loads alone ~700-900 us, together 2186 us, i.e. the two streams still add
-// up instead of overlapping, although tools/coissue*.hip shows independent v_fma/v_exp/v_max3
-// hiding completely under v_mfma_f32_32x32x16_bf16 at two waves per SIMD (only VOP3P packed-fp32
-// ops do not co-issue; none are left here).  What serialises them in situ is an open question
-// for the next round; selectable with SKIMI_ATTN_Q64=2.
+// STATUS: correct (same tests as the other two kernels) but NOT the default: 2186-2210 us vs 2098 us
+// (attention_q64.hip) on 4 x 10992 keys x 16 heads; selectable with SKIMI_ATTN_Q64=2.
+// What the experiments say (tools/coissue.hip, coissue2.hip, coissue3.hip; MI355X):
+//   * ablations here: softmax VALU stream alone 1285 us, MFMA + loads alone ~700-900 us, together
+//     2186 us: the two streams add up instead of overlapping; rebalancing the regions (2 + 6 MFMAs)
+//     and sched_group_barrier pipelines change nothing;
+//   * the q64 kernel with ONE workgroup per CU (one wave per SIMD) is only 18 % slower than with two:
+//     throughput is set by a single wave's in-order stream, the second wave barely fills gaps;
+//   * every VALU op kind of the softmax (v_fma / v_fmamk / v_exp / v_add / v_max3 / v_cvt_pk /
+//     v_perm / v_mov, RAW chains included) hides under v_mfma_f32_32x32x16_bf16 when it is
+//     independent of the MFMAs (only packed-fp32 VOP3P ops never co-issue);
+//   * a mini attention step without memory traffic reproduces the problem: MFMA stream 140 ns,
+//     softmax stream 131 ns, strictly interleaved (1 MFMA + its 8 VALU, order pinned) 288 ns; with
+//     the softmax input and P cut loose from the MFMAs 186 ns.  Feeding P (VALU-written registers)
+//     to the PV MFMAs and S (MFMA-written registers) to the softmax, even one iteration apart,
+//     brings back the sum.  Which interlock does that is the open question for the next round.
 #include <stdlib.h>
 
 #include <type_traits>

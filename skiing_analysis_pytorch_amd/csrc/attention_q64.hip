@@ -258,6 +258,17 @@ void attention_q64_dispatch(const AttnArgs& a, hipStream_t st) {
     const int nqb = (int)cdiv(a.seq_q, 256);
     const long nblk = (long)nqb * a.heads * a.batch;
     static const int dbg = getenv("SKIMI_ATTN_ABL") ? atoi(getenv("SKIMI_ATTN_ABL")) : 0;
+    // SKIMI_ATTN_LDSPAD (bytes of unused dynamic LDS): occupancy experiments, e.g. 65536 -> one workgroup per CU
+    static const size_t pad = getenv("SKIMI_ATTN_LDSPAD") ? (size_t)atol(getenv("SKIMI_ATTN_LDSPAD")) : 0;
+    if (pad) {
+        static bool once = false;
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_q64_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+            once = true;
+        }
+        hipLaunchKernelGGL(attn_q64_kernel<0>, dim3((unsigned)nblk), dim3(256), pad, st, a, nqb);
+        return;
+    }
     switch (dbg) {
         case 1: hipLaunchKernelGGL(attn_q64_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb); break;
         case 2: hipLaunchKernelGGL(attn_q64_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb); break;

@@ -33,6 +33,80 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, float seed) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float m = -1e30f, l = 0.f;
     const float c2 = 0.18f;
+    if (MODE == 4 || MODE == 5) {
+        // the MFMA stream of MODE 3 (S chain with 4 different A/B pairs, then PV) with the VALU work
+        // replaced by 8 independent asm ops per MFMA (MODE 4) or none (MODE 5): which side breaks co-issue?
+        float w[8];
+        for (int j = 0; j < 8; ++j) w[j] = seed + j;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c < 4) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[c], c == 0 ? zero : s, 0, 0, 0);
+                else o[c & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c - 4], pf[(c - 4) >> 1], o[c & 1], 0, 0, 0);
+                asm volatile("" : "+v"(s), "+v"(o[0]), "+v"(o[1]));
+                if (MODE == 4) {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        float& x = w[n];
+                        switch (n) {
+                            case 0: case 1: asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x) : "v"(seed)); break;
+                            case 2: case 3: asm volatile("v_exp_f32 %0, %0" : "+v"(x)); break;
+                            case 4: case 5: asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(seed)); break;
+                            case 6: asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(x) : "v"(seed)); break;
+                            default: asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x) : "v"(seed)); break;
+                        }
+                    }
+                }
+            }
+        }
+        for (int j = 0; j < 8; ++j) l += w[j];
+    } else
+    if (MODE == 3) {
+        // hand-chunked: source order = issue order at chunk granularity (sched_barrier(0) between
+        // chunks): chunk c = MFMA c of the iteration + its share of the previous tile's softmax
+        for (int it = 0; it < iters; ++it) {
+            bf16x8 pn[2] = {pf[0], pf[1]};
+            float mloc, nmb, l0 = 0.f, l1 = 0.f;
+#define MF(c)                                                                                               \
+    if ((c) < 4) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[c], (c) == 0 ? zero : s, 0, 0, 0);   \
+    else o[(c) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[(c) - 4], pf[((c) - 4) >> 1], o[(c) & 1], 0, 0, 0);
+#define EL(r)                                                                                               \
+    { float v = __builtin_amdgcn_exp2f(__builtin_fmaf(sp[r], c2, nmb)); if ((r) & 1) l1 += v; else l0 += v; sp[r] = v; }
+// every live value passes through an empty volatile asm: nothing can be moved across it
+#define FENCE asm volatile("" : "+v"(sp), "+v"(s), "+v"(o[0]), "+v"(o[1]), "+v"(pn[0]), "+v"(pn[1]), "+v"(l0), "+v"(l1), "+v"(nmb))
+#define CV(ks, j0)                                                                                          \
+    { pn[ks][j0] = (short)f2bf(sp[8 * (ks) + (j0)]); pn[ks][(j0) + 1] = (short)f2bf(sp[8 * (ks) + (j0) + 1]); }
+            MF(0)
+            mloc = sp[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mloc = __builtin_fmaxf(mloc, sp[r]);
+            m = __builtin_fmaxf(m, mloc);
+            nmb = -(m * c2);
+            FENCE;
+            MF(1) EL(0) EL(1) CV(0, 0)
+            FENCE;
+            MF(2) EL(2) EL(3) CV(0, 2) EL(4)
+            FENCE;
+            MF(3) EL(5) CV(0, 4) EL(6) EL(7) CV(0, 6)
+            FENCE;
+            MF(4) EL(8) EL(9) CV(1, 0)
+            FENCE;
+            MF(5) EL(10) EL(11) CV(1, 2) EL(12)
+            FENCE;
+            MF(6) EL(13) CV(1, 4) EL(14)
+            FENCE;
+            MF(7) EL(15) CV(1, 6)
+            l += l0 + l1;
+            FENCE;
+            pf[0] = pn[0]; pf[1] = pn[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sp[r] = s[r];
+#undef MF
+#undef EL
+#undef CV
+#undef FENCE
+        }
+    } else
     for (int it = 0; it < iters; ++it) {
         // MFMA stream A: S = K Q^T
         if (MODE != 2) {
@@ -123,6 +197,8 @@ int main() {
         printf("   sched_group_barrier 1 MFMA + N VALU:  N=6 %.1f  N=8 %.1f  N=10 %.1f  N=12 %.1f\n", run<0, 6>(out, blocks),
                run<0, 8>(out, blocks), run<0, 10>(out, blocks), run<0, 12>(out, blocks));
         // iglp_opt(1) is left out: hipcc (ROCm 7.2) runs out of memory on it for this loop
+        printf("   MODE-3 MFMA stream + 8 independent asm VALU per MFMA: %.1f   that MFMA stream alone: %.1f\n", run<4, 0>(out, blocks), run<5, 0>(out, blocks));
+        printf("   hand-chunked (sched_barrier between 1 MFMA + its VALU share): %.1f\n", run<3, 0>(out, blocks));
         printf("   iglp_opt(0), (2), (3): %.1f %.1f %.1f\n", run<0, -1>(out, blocks), run<0, -3>(out, blocks), run<0, -4>(out, blocks));
         printf("   softmax input independent of the MFMAs: both %.1f (grouped N=12: %.1f); P also not fed to PV: both %.1f (grouped %.1f)\n",
                run<0, 0, 0, 1>(out, blocks), run<0, 12, 0, 1>(out, blocks), run<0, 0, 0, 2>(out, blocks), run<0, 12, 0, 2>(out, blocks));
