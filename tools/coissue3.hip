@@ -61,19 +61,25 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, float seed) {
         }
         for (int j = 0; j < 8; ++j) l += w[j];
     } else
-    if (MODE == 3) {
+    if (MODE == 3 || MODE == 6) {   // MODE 6: the same with S and O accumulators in AGPRs (asm MFMA, "a" constraints)
         // hand-chunked: source order = issue order at chunk granularity (sched_barrier(0) between
         // chunks): chunk c = MFMA c of the iteration + its share of the previous tile's softmax
         for (int it = 0; it < iters; ++it) {
             bf16x8 pn[2] = {pf[0], pf[1]};
             float mloc, nmb, l0 = 0.f, l1 = 0.f;
 #define MF(c)                                                                                               \
-    if ((c) < 4) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[c], (c) == 0 ? zero : s, 0, 0, 0);   \
+    if (MODE == 6) {                                                                                        \
+        if ((c) == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(s) : "v"(kf[c]), "v"(qf[c]));                \
+        else if ((c) < 4) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(s) : "v"(kf[c]), "v"(qf[c]));           \
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[(c) & 1]) : "v"(vf[(c) - 4]), "v"(pf[((c) - 4) >> 1])); \
+    } else if ((c) < 4) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[c], (c) == 0 ? zero : s, 0, 0, 0);   \
     else o[(c) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[(c) - 4], pf[((c) - 4) >> 1], o[(c) & 1], 0, 0, 0);
 #define EL(r)                                                                                               \
     { float v = __builtin_amdgcn_exp2f(__builtin_fmaf(sp[r], c2, nmb)); if ((r) & 1) l1 += v; else l0 += v; sp[r] = v; }
 // every live value passes through an empty volatile asm: nothing can be moved across it
-#define FENCE asm volatile("" : "+v"(sp), "+v"(s), "+v"(o[0]), "+v"(o[1]), "+v"(pn[0]), "+v"(pn[1]), "+v"(l0), "+v"(l1), "+v"(nmb))
+#define FENCE                                                                                               \
+    if (MODE == 6) asm volatile("" : "+v"(sp), "+a"(s), "+a"(o[0]), "+a"(o[1]), "+v"(pn[0]), "+v"(pn[1]), "+v"(l0), "+v"(l1), "+v"(nmb)); \
+    else asm volatile("" : "+v"(sp), "+v"(s), "+v"(o[0]), "+v"(o[1]), "+v"(pn[0]), "+v"(pn[1]), "+v"(l0), "+v"(l1), "+v"(nmb))
 #define CV(ks, j0)                                                                                          \
     { pn[ks][j0] = (short)f2bf(sp[8 * (ks) + (j0)]); pn[ks][(j0) + 1] = (short)f2bf(sp[8 * (ks) + (j0) + 1]); }
             MF(0)
@@ -198,6 +204,7 @@ int main() {
                run<0, 8>(out, blocks), run<0, 10>(out, blocks), run<0, 12>(out, blocks));
         // iglp_opt(1) is left out: hipcc (ROCm 7.2) runs out of memory on it for this loop
         printf("   MODE-3 MFMA stream + 8 independent asm VALU per MFMA: %.1f   that MFMA stream alone: %.1f\n", run<4, 0>(out, blocks), run<5, 0>(out, blocks));
+        printf("   strictly interleaved with the accumulators in AGPRs: %.1f\n", run<6, 0>(out, blocks));
         printf("   hand-chunked (sched_barrier between 1 MFMA + its VALU share): %.1f\n", run<3, 0>(out, blocks));
         printf("   iglp_opt(0), (2), (3): %.1f %.1f %.1f\n", run<0, -1>(out, blocks), run<0, -3>(out, blocks), run<0, -4>(out, blocks));
         printf("   softmax input independent of the MFMAs: both %.1f (grouped N=12: %.1f); P also not fed to PV: both %.1f (grouped %.1f)\n",
