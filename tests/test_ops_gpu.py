@@ -183,7 +183,8 @@ def test_attention_f32(batch, seq, heads, hd):
     assert (out.cpu() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("batch,seq,heads", [(2, 77, 3), (1, 300, 2), (2, 1374, 4), (1, 2748, 2), (1, 64, 1), (1, 128, 1)])
+@pytest.mark.parametrize("batch,seq,heads", [(2, 77, 3), (1, 300, 2), (2, 1374, 4), (1, 2748, 2), (1, 64, 1), (1, 128, 1),
+                                              (3, 1, 2), (1, 65, 1), (2, 257, 2), (1, 513, 3)])
 def test_attention_bf16(batch, seq, heads):
     hd = 64
     qkv = _rand(batch * seq, 3 * heads * hd, seed=61).to(torch.bfloat16)
@@ -192,6 +193,32 @@ def test_attention_bf16(batch, seq, heads):
     ref = F.scaled_dot_product_attention(x[0], x[1], x[2]).transpose(1, 2).reshape(batch * seq, -1)
     err = (out.float().cpu() - ref).abs().max().item()
     assert err < 2e-2, err
+
+
+@pytest.mark.parametrize("variant", ["0", "2"])
+def test_attention_bf16_other_kernels(variant):
+    """The default is the 64-query kernel; SKIMI_ATTN_Q64=0 (32-query kernel) and =2 (skewed half-step
+    pipeline) stay selectable for A/B timing and must stay correct.  The switch is read once per
+    process, so each variant runs in a child process."""
+    import os, subprocess, sys
+    code = (
+        "import torch, torch.nn.functional as F\n"
+        "from skiing_analysis_pytorch_amd import ops\n"
+        "worst = 0.0\n"
+        "for batch, seq, heads in [(2, 77, 3), (1, 1374, 2), (2, 257, 2), (1, 64, 1)]:\n"
+        "    g = torch.Generator().manual_seed(61)\n"
+        "    qkv = torch.randn(batch * seq, 3 * heads * 64, generator=g).to(torch.bfloat16).cuda()\n"
+        "    out = ops.attention(qkv, batch, seq, heads, 64)\n"
+        "    x = qkv.float().cpu().reshape(batch, seq, 3, heads, 64).permute(2, 0, 3, 1, 4)\n"
+        "    ref = F.scaled_dot_product_attention(x[0], x[1], x[2]).transpose(1, 2).reshape(batch * seq, -1)\n"
+        "    worst = max(worst, (out.float().cpu() - ref).abs().max().item())\n"
+        "print('WORST', worst)\n")
+    env = dict(os.environ, SKIMI_ATTN_Q64=variant)
+    root = str(__import__("pathlib").Path(__file__).resolve().parent.parent)
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float(r.stdout.strip().split("WORST")[-1])
+    assert worst < 2e-2, worst
 
 
 def test_attention_bf16_online_softmax_rescale():
