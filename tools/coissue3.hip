@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, float seed) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float m = -1e30f, l = 0.f;
     const float c2 = 0.18f;
-    if (MODE == 4 || MODE == 5) {
+    if (MODE == 4 || MODE == 5 || MODE == 8) {   // MODE 8 = MODE 4 + the hand-off: the asm VALU ops consume copies of S made at the iteration end
         // the MFMA stream of MODE 3 (S chain with 4 different A/B pairs, then PV) with the VALU work
         // replaced by 8 independent asm ops per MFMA (MODE 4) or none (MODE 5): which side breaks co-issue?
         float w[8];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, float seed) {
                 if (c < 4) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[c], c == 0 ? zero : s, 0, 0, 0);
                 else o[c & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[c - 4], pf[(c - 4) >> 1], o[c & 1], 0, 0, 0);
                 asm volatile("" : "+v"(s), "+v"(o[0]), "+v"(o[1]));
-                if (MODE == 4) {
+                if (MODE == 4 || MODE == 8) {
 #pragma unroll
                     for (int n = 0; n < 8; ++n) {
                         float& x = w[n];
@@ -58,10 +58,14 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, float seed) {
                     }
                 }
             }
+            if (MODE == 8) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = s[j] + s[j + 8];   // VALU reads of MFMA-written registers
+            }
         }
         for (int j = 0; j < 8; ++j) l += w[j];
     } else
-    if (MODE == 3 || MODE == 6) {   // MODE 6: the same with S and O accumulators in AGPRs (asm MFMA, "a" constraints)
+    if (MODE == 3 || MODE == 6 || MODE == 7) {   // MODE 7: S goes to the softmax registers through LDS (ds_write / ds_read) instead of v_mov   // MODE 6: the same with S and O accumulators in AGPRs (asm MFMA, "a" constraints)
         // hand-chunked: source order = issue order at chunk granularity (sched_barrier(0) between
         // chunks): chunk c = MFMA c of the iteration + its share of the previous tile's softmax
         for (int it = 0; it < iters; ++it) {
@@ -105,8 +109,20 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, float seed) {
             l += l0 + l1;
             FENCE;
             pf[0] = pn[0]; pf[1] = pn[1];
+            if (MODE == 7) {
+                __shared__ __attribute__((aligned(16))) float xch[256 * 16];
+                float4* slot = reinterpret_cast<float4*>(xch) + threadIdx.x;   // [4][256] float4, conflict-free
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sp[r] = s[r];
+                for (int g = 0; g < 4; ++g) slot[g * 256] = make_float4(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t = slot[g * 256];
+                    sp[4 * g] = t.x; sp[4 * g + 1] = t.y; sp[4 * g + 2] = t.z; sp[4 * g + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sp[r] = s[r];
+            }
 #undef MF
 #undef EL
 #undef CV
@@ -160,6 +176,19 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, float seed) {
                 }
         }
         if (GRP < 0 && MODE == 0) __builtin_amdgcn_iglp_opt(-GRP - 1);   // GRP -1,-2,-3,-4 -> iglp_opt 0..3
+        if (GRP >= 100 && MODE == 0) {
+            // shaped pipelines: the max chain (8 max3) under the first two MFMAs, the 16 exp chains under the other six
+#define SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define MFM SG(0x008, 1)
+            if (GRP == 100) { MFM; SG(2, 5); MFM; SG(2, 5); MFM; SG(2, 11); MFM; SG(2, 11); MFM; SG(2, 11); MFM; SG(2, 11); MFM; SG(2, 11); MFM; SG(2, 11); }
+            if (GRP == 101) { MFM; SG(2, 5); MFM; SG(2, 5); MFM; SG(0x400, 3); SG(2, 8); MFM; SG(0x400, 3); SG(2, 8); MFM; SG(0x400, 3); SG(2, 8);
+                              MFM; SG(0x400, 3); SG(2, 8); MFM; SG(0x400, 2); SG(2, 8); MFM; SG(0x400, 2); SG(2, 8); }
+            if (GRP == 102) { MFM; SG(2, 5); MFM; SG(2, 5); MFM; SG(2, 4); SG(0x400, 3); SG(2, 4); MFM; SG(2, 4); SG(0x400, 3); SG(2, 4); MFM; SG(2, 4); SG(0x400, 3); SG(2, 4);
+                              MFM; SG(2, 4); SG(0x400, 3); SG(2, 4); MFM; SG(2, 4); SG(0x400, 2); SG(2, 4); MFM; SG(2, 4); SG(0x400, 2); SG(2, 4); }
+            if (GRP == 103) { MFM; SG(2, 9); MFM; SG(2, 10); MFM; SG(2, 10); MFM; SG(2, 10); MFM; SG(2, 10); MFM; SG(2, 10); MFM; SG(2, 10); MFM; SG(2, 10); }
+#undef SG
+#undef MFM
+        } else
         if (GRP > 0 && MODE == 0) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
@@ -203,9 +232,12 @@ int main() {
         printf("   sched_group_barrier 1 MFMA + N VALU:  N=6 %.1f  N=8 %.1f  N=10 %.1f  N=12 %.1f\n", run<0, 6>(out, blocks),
                run<0, 8>(out, blocks), run<0, 10>(out, blocks), run<0, 12>(out, blocks));
         // iglp_opt(1) is left out: hipcc (ROCm 7.2) runs out of memory on it for this loop
-        printf("   MODE-3 MFMA stream + 8 independent asm VALU per MFMA: %.1f   that MFMA stream alone: %.1f\n", run<4, 0>(out, blocks), run<5, 0>(out, blocks));
+        printf("   MODE-3 MFMA stream + 8 independent asm VALU per MFMA: %.1f   that MFMA stream alone: %.1f   with S copied into the VALU registers each iteration: %.1f\n",
+               run<4, 0>(out, blocks), run<5, 0>(out, blocks), run<8, 0>(out, blocks));
+        printf("   strictly interleaved, S handed to the softmax through LDS: %.1f\n", run<7, 0>(out, blocks));
         printf("   strictly interleaved with the accumulators in AGPRs: %.1f\n", run<6, 0>(out, blocks));
         printf("   hand-chunked (sched_barrier between 1 MFMA + its VALU share): %.1f\n", run<3, 0>(out, blocks));
+        printf("   shaped sched_group_barrier pipelines P0..P3: %.1f %.1f %.1f %.1f\n", run<0, 100>(out, blocks), run<0, 101>(out, blocks), run<0, 102>(out, blocks), run<0, 103>(out, blocks));
         printf("   iglp_opt(0), (2), (3): %.1f %.1f %.1f\n", run<0, -1>(out, blocks), run<0, -3>(out, blocks), run<0, -4>(out, blocks));
         printf("   softmax input independent of the MFMAs: both %.1f (grouped N=12: %.1f); P also not fed to PV: both %.1f (grouped %.1f)\n",
                run<0, 0, 0, 1>(out, blocks), run<0, 12, 0, 1>(out, blocks), run<0, 0, 0, 2>(out, blocks), run<0, 12, 0, 2>(out, blocks));
