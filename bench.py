@@ -67,7 +67,7 @@ def main():
     sd = W.make_vggt_state_dict(cfg, seed=0, device=dev)      # random-init weights of that architecture
     model.load_state_dict(sd)
     cpu_sd = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # CPU legs: rank 0 at N = 1 only
         cpu_sd = {k: v.cpu() for k, v in sd.items()}
     del sd
     torch.cuda.empty_cache()
@@ -149,7 +149,7 @@ def main():
                             "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(B),
                             "avg_launch_us": avg_s * 1e6, "launches": int(n.value),
                             "flops_per_launch": flops_per_launch}
-    if rank == 0:
+    if rank == 0 and world == 1:
         line["vp3d"] = vp3d_leg(dev, cpu=not args.no_cpu_baseline)
     if rank == 0 and cpu_sd is not None:
         line["cpu_baseline"], line["parity_vs_cpu_oracle"] = cpu_baseline(cpu_sd, cfg, args.cpu_views, model, dev)
