@@ -88,7 +88,9 @@ typedef struct skimi_gemm_desc {
     int32_t prec;             /* SKIMI_PREC_* */
     /* A gather: a_mode 0 = plain rows; 1 = implicit im2col of a channels-last image
      * [cN, cH, cW, cC] with a KH x KW window (tap-major K: k = (ky*KW+kx)*cC + c),
-     * M = cN*OH*OW, K = KH*KW*cC, cC % BK == 0 (BK = 64 for BF16, 32 for BF16X3) */
+     * M = cN*OH*OW, K = KH*KW*cC, cC % BK == 0 (BK = 64 for BF16, 32 for BF16X3);
+     * 2 = the same gather with slice-major K (BF16X3 only, cC % 32 == 0):
+     * k = ((c / 32) * KH*KW + ky*KW + kx) * 32 + c % 32, i.e. weights [N][cC/32][KH][KW][32] */
     int32_t a_mode;
     int32_t cN, cH, cW, cC, KH, KW, stride, pad, dil, OH, OW;
     /* epilogue: v = acc + bias[n]; v = act(v); v *= gamma[n]; v += resid[m', n];

@@ -180,6 +180,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         if (p.a_mode != 0) {                                                                            \
             int tap = k0 / p.cC;                                                                        \
             cin0 = k0 - tap * p.cC;                                                                     \
+            if (p.a_mode == 2) { /* slice-major K: k = ((c / 32) * taps + tap) * 32 + c % 32 */         \
+                const int u = k0 >> 5, nt = p.KH * p.KW;                                                \
+                const int cs = u / nt;                                                                  \
+                tap = u - cs * nt;                                                                      \
+                cin0 = cs * 32 + (k0 & 31);                                                             \
+            }                                                                                           \
             int ky = tap / p.KW;                                                                        \
             int kx = tap - ky * p.KW;                                                                   \
             tap_dy = ky * p.dil;                                                                        \
@@ -399,6 +405,7 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     const int BK = d->prec == SKIMI_PREC_BF16 ? 64 : 32;
     if (d->a_mode != 0) {
         SKIMI_CHECK_ARG(d->cC % BK == 0, "skimi_gemm: conv gather needs cC %% %d == 0 (cC=%d)", BK, d->cC);
+        SKIMI_CHECK_ARG(d->a_mode != 2 || BK == 32, "skimi_gemm: slice-major conv weights (a_mode 2) need a K-tile of 32 (fp32-accurate mode)");
         SKIMI_CHECK_ARG(d->K == d->KH * d->KW * d->cC, "skimi_gemm: K != KH*KW*cC");
         SKIMI_CHECK_ARG((long)d->cN * d->OH * d->OW == d->M, "skimi_gemm: M != cN*OH*OW");
         SKIMI_CHECK_ARG((d->OH - 1) * d->stride - d->pad + (d->KH - 1) * d->dil < d->cH + d->pad &&

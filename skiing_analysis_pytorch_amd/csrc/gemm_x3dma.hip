@@ -130,8 +130,14 @@ __global__ __launch_bounds__(512, 2) void gemm_x3dma_kernel(const GemmArgs p, co
         const int k0 = kt * BK;
         int tap_dy = 0, tap_dx = 0, cin0 = k0;
         if (p.a_mode != 0) {
-            const int tap = k0 / p.cC;
+            int tap = k0 / p.cC;
             cin0 = k0 - tap * p.cC;
+            if (p.a_mode == 2) {   // slice-major K: k = ((c / 32) * taps + tap) * 32 + c % 32
+                const int u = k0 >> 5, nt = p.KH * p.KW;
+                const int cs = u / nt;
+                tap = u - cs * nt;
+                cin0 = cs * 32;
+            }
             const int ky = tap / p.KW;
             tap_dy = ky * p.dil;
             tap_dx = (tap - ky * p.KW) * p.dil;

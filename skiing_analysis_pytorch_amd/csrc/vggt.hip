@@ -19,6 +19,8 @@
 #include <string>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "kernels.h"
@@ -44,7 +46,7 @@ struct BlockW {
     float *ls1 = nullptr, *ls2 = nullptr;
     float *qn_w = nullptr, *qn_b = nullptr, *kn_w = nullptr, *kn_b = nullptr;
 };
-struct ConvW { Lin lin; int k = 1, stride = 1, pad = 0, cin = 0; };
+struct ConvW { Lin lin; int k = 1, stride = 1, pad = 0, cin = 0; int kmode = 1; };   // kmode: a_mode of the gather (1 tap-major, 2 slice-major K)
 struct FusionW { Lin out_conv; ConvW r1c1, r1c2, r2c1, r2c2; bool has_r1 = false; };
 struct DptW {
     LNw norm;
@@ -210,8 +212,11 @@ struct Packer {
         float* perm = src;
         float* tmp = nullptr;
         if (k > 1) {
+            // fp32-accurate convs run on K-tiles of 32: order K slice-major there (see permute_conv_kernel)
+            static const int force_tap_major = getenv("SKIMI_CONV_TAP_MAJOR") ? atoi(getenv("SKIMI_CONV_TAP_MAJOR")) : 0;   // A/B timing
+            c.kmode = (prec == SKIMI_PREC_BF16X3 && Ci % 32 == 0 && !force_tap_major) ? 2 : 1;
             if (hipMalloc((void**)&tmp, (size_t)Co * Ci * k * k * 4) != hipSuccess) { rc = SKIMI_ERR_HIP; return c; }
-            if ((rc = permute_conv_launch(src, tmp, Co, Ci, k, k, st))) return c;
+            if ((rc = permute_conv_launch(src, tmp, Co, Ci, k, k, st, c.kmode == 2))) return c;
             perm = tmp;
         }
         c.lin = pack_matrix(perm, Co, Ci * k * k, prec);
@@ -342,7 +347,7 @@ struct Ctx {
     }
     void conv_geom(skimi_gemm_desc& d, const ConvW& c, int N, int H, int W, int OH, int OW) {
         if (c.k == 1 && c.stride == 1) return;   // plain rows
-        d.a_mode = 1;
+        d.a_mode = c.kmode;
         d.cN = N; d.cH = H; d.cW = W; d.cC = c.cin; d.KH = c.k; d.KW = c.k;
         d.stride = c.stride; d.pad = c.pad; d.dil = 1; d.OH = OH; d.OW = OW;
     }

@@ -318,18 +318,35 @@ int f32_to_bf16_launch(const float* in, void* out, long n, hipStream_t st) {
 }
 
 // Conv2d weight [Co, Ci, kh, kw] -> [Co, kh, kw, Ci]  (tap-major K of the implicit gather)
-__global__ void permute_conv_kernel(const float* __restrict__ in, float* __restrict__ out, int Co, int Ci, int kh, int kw) {
+__global__ void permute_conv_kernel(const float* __restrict__ in, float* __restrict__ out, int Co, int Ci, int kh, int kw,
+                                    int slice_major) {
     const long n = (long)Co * Ci * kh * kw;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int ci = (int)(i % Ci);
-        const int x = (int)((i / Ci) % kw);
-        const int y = (int)((i / ((long)Ci * kw)) % kh);
-        const long co = i / ((long)Ci * kw * kh);
+        int ci, x, y;
+        long co;
+        if (slice_major) {
+            // [co][ci / 32][y][x][ci % 32]: a K-tile of 32 is one (channel slice, tap); the 9 taps of a
+            // slice are consecutive K-tiles, so their shifted input windows are re-read from L1 / L2
+            // while still hot (tap-major order re-reads a window only after a whole pass over Cin)
+            const int c32 = (int)(i % 32);
+            x = (int)((i / 32) % kw);
+            y = (int)((i / (32L * kw)) % kh);
+            const int cs = (int)((i / (32L * kw * kh)) % (Ci / 32));
+            co = i / ((long)Ci * kw * kh);
+            ci = cs * 32 + c32;
+        } else {
+            ci = (int)(i % Ci);
+            x = (int)((i / Ci) % kw);
+            y = (int)((i / ((long)Ci * kw)) % kh);
+            co = i / ((long)Ci * kw * kh);
+        }
         out[i] = in[((co * Ci + ci) * kh + y) * kw + x];
     }
 }
-int permute_conv_launch(const float* in, float* out, int Co, int Ci, int kh, int kw, hipStream_t st) {
-    hipLaunchKernelGGL(permute_conv_kernel, dim3(grid_for((long)Co * Ci * kh * kw)), dim3(256), 0, st, in, out, Co, Ci, kh, kw);
+int permute_conv_launch(const float* in, float* out, int Co, int Ci, int kh, int kw, hipStream_t st, int slice_major) {
+    SKIMI_CHECK_ARG(!slice_major || Ci % 32 == 0, "slice-major conv weights need Cin %% 32 == 0");
+    hipLaunchKernelGGL(permute_conv_kernel, dim3(grid_for((long)Co * Ci * kh * kw)), dim3(256), 0, st, in, out, Co, Ci, kh, kw,
+                       slice_major);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }

@@ -42,7 +42,7 @@ def gemm(a, w, *, prec=PREC_BF16X3, bias=None, gamma=None, resid=None, act=ACT_N
     d.ldw = w.stride(0)
     d.prec = prec
     if conv is not None:
-        d.a_mode = 1
+        d.a_mode = 2 if conv.get("slice_major") else 1   # 2: weights packed [Cout][Cin/32][ky][kx][32]
         d.cN, d.cH, d.cW, d.cC = conv["N"], conv["H"], conv["W"], conv["C"]
         d.KH, d.KW, d.stride, d.pad, d.dil = conv["KH"], conv["KW"], conv["stride"], conv["pad"], conv["dil"]
         d.OH, d.OW = conv["OH"], conv["OW"]

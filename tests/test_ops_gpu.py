@@ -97,6 +97,33 @@ def test_gemm_conv_gather(cfg, prec):
     assert _rel(out, ref_cl) < (2e-5 if prec == PREC_BF16X3 else 1e-2)
 
 
+@pytest.mark.parametrize("cfg", [dict(H=37, W=37, C=64, Co=96, k=3, s=1, p=1), dict(H=19, W=23, C=128, Co=32, k=3, s=2, p=1),
+                                 dict(H=30, W=30, C=256, Co=256, k=3, s=1, p=1)])
+def test_gemm_conv_gather_slice_major_k(cfg):
+    """a_mode 2: the same 3x3 gather with K ordered [Cin/32][ky][kx][32] (weights packed to match); the last
+    shape (Cout 256, pre-split planes) takes the LDS-DMA bf16x3 kernel."""
+    H, W_, Cc, Co, k, s, p = (cfg[x] for x in ("H", "W", "C", "Co", "k", "s", "p"))
+    n = 2
+    x = _rand(n, H, W_, Cc, seed=20)
+    w = _rand(Co, Cc, k, k, seed=21, scale=1 / math.sqrt(Cc * k * k))
+    b = _rand(Co, seed=22)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, stride=s, padding=p)
+    OH, OW = ref.shape[2], ref.shape[3]
+    # [Co, Cin/32, ky, kx, 32]
+    wp = w.reshape(Co, Cc // 32, 32, k, k).permute(0, 1, 3, 4, 2).reshape(Co, k * k * Cc).contiguous()
+    conv = dict(N=n, H=H, W=W_, C=Cc, KH=k, KW=k, stride=s, pad=p, dil=1, OH=OH, OW=OW, slice_major=True)
+    ref_cl = ref.permute(0, 2, 3, 1).reshape(-1, Co)
+    out = ops.gemm(x.reshape(-1, Cc), wp, prec=PREC_BF16X3, bias=b, conv=conv)
+    assert _rel(out, ref_cl) < 2e-5
+    if Co >= 256:
+        scratch = torch.empty(x.numel(), dtype=torch.float32, device=DEV)
+        out2 = ops.gemm(x.reshape(-1, Cc), wp, prec=PREC_BF16X3, bias=b, conv=conv, w_split=ops.split_planes(wp), x3_scratch=scratch)
+        assert _rel(out2, ref_cl) < 2e-5
+    # plain bf16 tiles are 64 deep: slice-major weights are refused, not mis-read
+    with pytest.raises(Exception):
+        ops.gemm(x.reshape(-1, Cc).to(torch.bfloat16), wp.to(torch.bfloat16), prec=PREC_BF16, bias=b, conv=conv)
+
+
 def test_gemm_pixel_shuffle_convtranspose():
     n, H, W_, Cc, Co, s = 2, 9, 7, 64, 32, 4
     x = _rand(n, H, W_, Cc, seed=30)
