@@ -146,6 +146,16 @@ int skimi_split_planes(const float* x, int64_t ld, int64_t rows, int32_t C, void
 
 int skimi_gemm(const skimi_gemm_desc* d, void* stream);
 
+/* Direct 3x3 convolution (stride 1, pad 1) of a channels-last image to 32 output channels in the
+ * fp32-accurate mode: the last conv of the DPT heads at full resolution
+ * (vggt/vggt/heads/dpt_head.py:224-235, scratch.output_conv2[0]).  The input comes as the two bf16
+ * planes of skimi_split_planes ([F, H, W, C] each, C % 32 == 0), the weights in the packed layout
+ * that skimi_conv3x3_n32_pack makes of the reference's [32, C, 3, 3] tensor
+ * (2 * 32 * C * 9 bf16).  out: fp32 [F, H, W, 32]; bias [32] or NULL; relu != 0 applies ReLU. */
+int skimi_conv3x3_n32_pack(const float* w, void* packed, int32_t C, void* stream);
+int skimi_conv3x3_n32(const void* in_hi, const void* in_lo, const void* packed_w, const float* bias, float* out,
+                      int32_t F, int32_t H, int32_t W, int32_t C, int32_t relu, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Row-wise ops on token streams                                              */
 /* ------------------------------------------------------------------------- */

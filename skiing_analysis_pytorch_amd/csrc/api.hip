@@ -100,6 +100,17 @@ int skimi_gemm(const skimi_gemm_desc* d, void* stream) {
                          d->force_splitk);
 }
 
+int skimi_conv3x3_n32_pack(const float* w, void* packed, int32_t C, void* stream) {
+    SKIMI_CHECK_ARG(w && packed && C > 0, "skimi_conv3x3_n32_pack: bad arguments");
+    return conv_direct_pack_launch(w, (unsigned short*)packed, C, (hipStream_t)stream);
+}
+
+int skimi_conv3x3_n32(const void* in_hi, const void* in_lo, const void* packed_w, const float* bias, float* out,
+                      int32_t F, int32_t H, int32_t W, int32_t C, int32_t relu, void* stream) {
+    return conv_direct_n32_launch((const unsigned short*)in_hi, (const unsigned short*)in_lo,
+                                  (const unsigned short*)packed_w, bias, out, F, H, W, C, relu, (hipStream_t)stream);
+}
+
 int skimi_split_planes(const float* x, int64_t ld, int64_t rows, int32_t C, void* hi, void* lo, void* stream) {
     SKIMI_CHECK_ARG(x && hi && lo && rows > 0 && C > 0, "skimi_split_planes: bad arguments");
     return split_planes_launch(x, (long)ld, (long)rows, C, hi, lo, (hipStream_t)stream);

@@ -57,6 +57,7 @@ struct DptW {
     FusionW ref[4];     // ref[0] = refinenet1 ... ref[3] = refinenet4
     ConvW oc1, oc2a;
     float *oc2b_w = nullptr, *oc2b_b = nullptr;
+    unsigned short* oc2a_direct = nullptr;   // conv_direct.hip weight layout of oc2a (fp32-accurate heads)
     int n_out = 0, features = 0, oc[4] = {0, 0, 0, 0};
     bool feature_only = false, pos_embed = true;
     int down_ratio = 1;
@@ -298,6 +299,14 @@ struct Packer {
         } else {
             d.oc1 = conv(p + ".scratch.output_conv1", features / 2, features, 3, 1, 1, prec, true);
             d.oc2a = conv(p + ".scratch.output_conv2.0", 32, features / 2, 3, 1, 1, prec, true);
+            if (!rc && prec == SKIMI_PREC_BF16X3 && (features / 2) % 32 == 0) {
+                // the full-resolution 3x3 -> 32 conv runs as a direct convolution (conv_direct.hip)
+                const int Ci = features / 2;
+                float* src = raw(p + ".scratch.output_conv2.0.weight", (int64_t)32 * Ci * 9);
+                d.oc2a_direct = (unsigned short*)dmalloc((size_t)32 * Ci * 9 * 2 * 2);
+                if (!rc && d.oc2a_direct) rc = conv_direct_pack_launch(src, d.oc2a_direct, Ci, st);
+                if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = SKIMI_ERR_HIP;
+            }
             d.oc2b_w = keep(p + ".scratch.output_conv2.2.weight", (int64_t)n_out * 32);
             d.oc2b_b = keep(p + ".scratch.output_conv2.2.bias", n_out);
         }
@@ -528,17 +537,29 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
         c.gemm(d);
     }
     const int Ho = ph * c.h->cfg.patch_size / w.down_ratio, Wo = pw * c.h->cfg.patch_size / w.down_ratio;
-    void* c1u = c.ar.alloc((size_t)F * Ho * Wo * f2 * es);
-    {
-        // upsample to the output size with the UV positional embedding added in the same pass
-        const UvTab* t = w.pos_embed ? find_uv(c.h, Wo, Ho, f2) : nullptr;
-        if (w.pos_embed && !t && !c.rc && !c.dry()) { set_error("uv table missing"); c.rc = SKIMI_ERR_STATE; }
+    const UvTab* uvt = w.pos_embed ? find_uv(c.h, Wo, Ho, f2) : nullptr;
+    if (w.pos_embed && !uvt && !c.rc && !c.dry()) { set_error("uv table missing"); c.rc = SKIMI_ERR_STATE; }
+    static const int no_direct = getenv("SKIMI_CONV_DIRECT") ? !atoi(getenv("SKIMI_CONV_DIRECT")) : 0;   // A/B timing
+    const bool direct = !w.feature_only && w.oc2a_direct != nullptr && adt == SKIMI_F32 && !no_direct;
+    void* c2 = nullptr;
+    if (direct) {
+        // upsample (+ UV embedding) straight into bf16 hi / lo planes, then the direct 3x3 -> 32 conv
+        const size_t pe = (size_t)F * Ho * Wo * f2;
+        unsigned short* hi = (unsigned short*)c.ar.alloc(pe * 2);
+        unsigned short* lo = (unsigned short*)c.ar.alloc(pe * 2);
+        c2 = c.ar.alloc((size_t)F * Ho * Wo * 32 * es);
         if (!c.rc && !c.dry())
-            c.rc = bilinear_ac_launch(c1, c1u, adt, F, h1, w1, Ho, Wo, f2, c.st, t ? t->tx : nullptr, t ? t->ty : nullptr);
-    }
-    if (w.feature_only) return c1u;   // caller releases the arena
-    void* c2 = c.ar.alloc((size_t)F * Ho * Wo * 32 * es);
-    {
+            c.rc = bilinear_ac_planes_launch((const float*)c1, hi, lo, F, h1, w1, Ho, Wo, f2, c.st, uvt ? uvt->tx : nullptr,
+                                             uvt ? uvt->ty : nullptr);
+        if (!c.rc && !c.dry())
+            c.rc = conv_direct_n32_launch(hi, lo, w.oc2a_direct, w.oc2a.lin.b, (float*)c2, F, Ho, Wo, f2, 1, c.st);
+    } else {
+        void* c1u = c.ar.alloc((size_t)F * Ho * Wo * f2 * es);
+        // upsample to the output size with the UV positional embedding added in the same pass
+        if (!c.rc && !c.dry())
+            c.rc = bilinear_ac_launch(c1, c1u, adt, F, h1, w1, Ho, Wo, f2, c.st, uvt ? uvt->tx : nullptr, uvt ? uvt->ty : nullptr);
+        if (w.feature_only) return c1u;   // caller releases the arena
+        c2 = c.ar.alloc((size_t)F * Ho * Wo * 32 * es);
         auto d = c.desc(w.oc2a.lin, c1u, adt, f2, F * Ho * Wo, c2, adt, 32);
         c.conv_geom(d, w.oc2a, F, Ho, Wo, Ho, Wo);
         d.act = SKIMI_ACT_RELU;

@@ -110,6 +110,22 @@ def attention(qkv, batch, seq, heads, head_dim):
     return out
 
 
+def conv3x3_n32(x, w, bias=None, relu=False):
+    """Direct fp32-accurate 3x3 conv (stride 1, pad 1) to 32 channels.  x: fp32 [F, H, W, C] channels-last,
+    w: the reference's [32, C, 3, 3] fp32 weight -> fp32 [F, H, W, 32]."""
+    _require_cuda(x, w, bias)
+    F_, H, W_, Cc = x.shape
+    assert w.shape == (32, Cc, 3, 3) and Cc % 32 == 0
+    planes = split_planes(x.reshape(-1, Cc).contiguous())
+    packed = torch.empty(2 * 32 * Cc * 9, dtype=torch.bfloat16, device=x.device)
+    st = _lib.current_stream()
+    check(lib().skimi_conv3x3_n32_pack(ptr(w.contiguous()), ptr(packed), Cc, st), "skimi_conv3x3_n32_pack")
+    out = torch.empty((F_, H, W_, 32), dtype=torch.float32, device=x.device)
+    check(lib().skimi_conv3x3_n32(ptr(planes[0]), ptr(planes[1]), ptr(packed), ptr(bias), ptr(out), F_, H, W_, Cc,
+                                  1 if relu else 0, st), "skimi_conv3x3_n32")
+    return out
+
+
 def split_planes(x):
     """fp32 [rows, C] -> bf16 [2, rows, C] (hi, lo) with hi + lo ~= x to ~2^-17 relative."""
     _require_cuda(x)

@@ -124,6 +124,21 @@ def test_gemm_conv_gather_slice_major_k(cfg):
         ops.gemm(x.reshape(-1, Cc).to(torch.bfloat16), wp.to(torch.bfloat16), prec=PREC_BF16, bias=b, conv=conv)
 
 
+@pytest.mark.parametrize("F_,H,W_,Cc,relu", [(2, 16, 16, 32, False), (1, 37, 53, 128, True), (3, 518 // 7, 70, 64, True)])
+def test_conv3x3_n32_direct(F_, H, W_, Cc, relu):
+    """LDS halo-tile direct convolution of the DPT output stage: interior tiles, ragged right / bottom
+    tiles, zero padding at every border, several 32-channel slices."""
+    x = _rand(F_, H, W_, Cc, seed=30)
+    w = _rand(32, Cc, 3, 3, seed=31, scale=1 / math.sqrt(Cc * 9))
+    b = _rand(32, seed=32)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    out = ops.conv3x3_n32(x, w, b, relu=relu)
+    assert out.shape == (F_, H, W_, 32)
+    assert _rel(out, ref.permute(0, 2, 3, 1)) < 2e-5
+
+
 def test_gemm_pixel_shuffle_convtranspose():
     n, H, W_, Cc, Co, s = 2, 9, 7, 64, 32, 4
     x = _rand(n, H, W_, Cc, seed=30)
