@@ -62,6 +62,7 @@ struct ConvDirectArgs {
     const float* bias;             // [32] or null
     float* out;                    // [F][H][W][32]
     int F, H, W, C, relu, tiles_x, tiles_y;
+    long px_stride;                // elements between pixels in a plane (C for separate planes, 2C for [hi | lo] pixel records)
 };
 
 __global__ __launch_bounds__(512, 2) void conv_direct_n32_kernel(const ConvDirectArgs p) {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void conv_direct_n32_kernel(const ConvDirec
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
             const int sc = (lane & 3) ^ ((px >> 2) & 3);
             if (px < CD_WIN && y >= 0 && y < p.H && x >= 0 && x < p.W)
-                in_off[j] = (((long)f * p.H + y) * p.W + x) * p.C + sc * 8;
+                in_off[j] = (((long)f * p.H + y) * p.W + x) * p.px_stride + sc * 8;
         }
     }
     int w_off[3], w_piece[3];
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(512, 2) void conv_direct_n32_kernel(const ConvDirec
 }
 
 int conv_direct_n32_launch(const unsigned short* in_hi, const unsigned short* in_lo, const unsigned short* w_packed,
-                           const float* bias, float* out, int F, int H, int W, int C, int relu, hipStream_t st) {
+                           const float* bias, float* out, int F, int H, int W, int C, int relu, hipStream_t st,
+                           long px_stride) {
     SKIMI_CHECK_ARG(in_hi && in_lo && w_packed && out, "conv_direct: null buffer");
     SKIMI_CHECK_ARG(C % 32 == 0 && C >= 32 && F > 0 && H > 0 && W > 0, "conv_direct: bad shape");
     SKIMI_CHECK_ARG((((uintptr_t)in_hi | (uintptr_t)in_lo | (uintptr_t)w_packed) & 15) == 0, "conv_direct: 16-B alignment");
@@ -221,6 +223,7 @@ int conv_direct_n32_launch(const unsigned short* in_hi, const unsigned short* in
     ConvDirectArgs a;
     a.in_hi = in_hi; a.in_lo = in_lo; a.w = w_packed; a.bias = bias; a.out = out;
     a.F = F; a.H = H; a.W = W; a.C = C; a.relu = relu;
+    a.px_stride = px_stride > 0 ? px_stride : C;
     a.tiles_x = (int)cdiv(W, 16);
     a.tiles_y = (int)cdiv(H, 16);
     const long nblk = (long)F * a.tiles_x * a.tiles_y;

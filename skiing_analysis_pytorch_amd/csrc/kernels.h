@@ -34,7 +34,8 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st);
 // conv_direct.hip: 3x3, Cin % 32 == 0 -> 32 channels, pad 1, fp32-accurate, on bf16 hi/lo planes
 int conv_direct_pack_launch(const float* w, unsigned short* out, int Cin, hipStream_t st);
 int conv_direct_n32_launch(const unsigned short* in_hi, const unsigned short* in_lo, const unsigned short* w_packed,
-                           const float* bias, float* out, int F, int H, int W, int C, int relu, hipStream_t st);
+                           const float* bias, float* out, int F, int H, int W, int C, int relu, hipStream_t st,
+                           long px_stride = 0);   // 0: separate planes [.., C]; 2C: pixel records [hi C | lo C]
 void attention_q64_dispatch(const AttnArgs& a, hipStream_t st);    // attention_q64.hip: 64 queries per wave
 void attention_pipe_dispatch(const AttnArgs& a, hipStream_t st);   // attention_pipe.hip: skewed half-step pipeline
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,

@@ -545,14 +545,14 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
     if (direct) {
         // upsample (+ UV embedding) straight into bf16 hi / lo planes, then the direct 3x3 -> 32 conv
         const size_t pe = (size_t)F * Ho * Wo * f2;
-        unsigned short* hi = (unsigned short*)c.ar.alloc(pe * 2);
-        unsigned short* lo = (unsigned short*)c.ar.alloc(pe * 2);
+        unsigned short* rec = (unsigned short*)c.ar.alloc(pe * 4);   // [pixel][hi f2 | lo f2]
         c2 = c.ar.alloc((size_t)F * Ho * Wo * 32 * es);
         if (!c.rc && !c.dry())
-            c.rc = bilinear_ac_planes_launch((const float*)c1, hi, lo, F, h1, w1, Ho, Wo, f2, c.st, uvt ? uvt->tx : nullptr,
+            c.rc = bilinear_ac_planes_launch((const float*)c1, rec, F, h1, w1, Ho, Wo, f2, c.st, uvt ? uvt->tx : nullptr,
                                              uvt ? uvt->ty : nullptr);
         if (!c.rc && !c.dry())
-            c.rc = conv_direct_n32_launch(hi, lo, w.oc2a_direct, w.oc2a.lin.b, (float*)c2, F, Ho, Wo, f2, 1, c.st);
+            c.rc = conv_direct_n32_launch(rec, rec + f2, w.oc2a_direct, w.oc2a.lin.b, (float*)c2, F, Ho, Wo, f2, 1, c.st,
+                                          2L * f2);
     } else {
         void* c1u = c.ar.alloc((size_t)F * Ho * Wo * f2 * es);
         // upsample to the output size with the UV positional embedding added in the same pass

@@ -144,63 +144,69 @@ __global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ 
     }
 }
 
-// the same resize (+ optional UV embedding) written as bf16 hi / lo planes of the fp32 result
-// (hi = bf16(v), lo = bf16(v - hi)): the input format of conv_direct.hip, same bytes as fp32
+// the same resize (+ optional UV embedding) written as bf16 hi / lo halves of the fp32 result
+// (hi = bf16(v), lo = bf16(v - hi)), one [hi C | lo C] record per pixel: the input format of
+// conv_direct.hip, same bytes and the same single write stream as the fp32 map
 __global__ __launch_bounds__(256) void bilinear_ac_planes_kernel(const float* __restrict__ in,
-                                                                 unsigned short* __restrict__ out_hi,
-                                                                 unsigned short* __restrict__ out_lo, int N, int h, int w,
+                                                                 unsigned short* __restrict__ out, int N, int h, int w,
                                                                  int H, int W, int C, const float* __restrict__ tabx,
                                                                  const float* __restrict__ taby) {
-    const int C4 = C / 4;
-    const long total = (long)N * H * W * C4;
+    // 8 channels per thread: 16-B stores into each plane
+    const int C8 = C / 8;
+    const long total = (long)N * H * W * C8;
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c4 = (int)(i % C4);
-        const int X = (int)((i / C4) % W);
-        const int Y = (int)((i / ((long)C4 * W)) % H);
-        const long n = i / ((long)C4 * W * H);
+        const int c8 = (int)(i % C8);
+        const int X = (int)((i / C8) % W);
+        const int Y = (int)((i / ((long)C8 * W)) % H);
+        const long n = i / ((long)C8 * W * H);
         const float fy = sy * Y, fx = sx * X;
         const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
         const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
         const float ly1 = fminf(fmaxf(fy - y0, 0.f), 1.f), lx1 = fminf(fmaxf(fx - x0, 0.f), 1.f);
         const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-        const float* base = in + n * (long)h * w * C + c4 * 4;
-        const float4 p00 = *reinterpret_cast<const float4*>(base + ((long)y0 * w + x0) * C);
-        const float4 p01 = *reinterpret_cast<const float4*>(base + ((long)y0 * w + x1) * C);
-        const float4 p10 = *reinterpret_cast<const float4*>(base + ((long)y1 * w + x0) * C);
-        const float4 p11 = *reinterpret_cast<const float4*>(base + ((long)y1 * w + x1) * C);
-        float r[4];
-        r[0] = ly0 * (lx0 * p00.x + lx1 * p01.x) + ly1 * (lx0 * p10.x + lx1 * p11.x);
-        r[1] = ly0 * (lx0 * p00.y + lx1 * p01.y) + ly1 * (lx0 * p10.y + lx1 * p11.y);
-        r[2] = ly0 * (lx0 * p00.z + lx1 * p01.z) + ly1 * (lx0 * p10.z + lx1 * p11.z);
-        r[3] = ly0 * (lx0 * p00.w + lx1 * p01.w) + ly1 * (lx0 * p10.w + lx1 * p11.w);
-        if (tabx != nullptr) {
-            const int half = C / 2, c = c4 * 4;
-            const float4 e = *reinterpret_cast<const float4*>(c < half ? tabx + (long)X * half + c
-                                                                        : taby + (long)Y * half + (c - half));
-            r[0] += e.x; r[1] += e.y; r[2] += e.z; r[3] += e.w;
-        }
-        bf16x4 hi, lo;
+        const float* base = in + n * (long)h * w * C + c8 * 8;
+        float p00[8], p01[8], p10[8], p11[8];
+        auto ld8 = [&](const float* q, float* d) {
+            const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+            d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+        };
+        ld8(base + ((long)y0 * w + x0) * C, p00);
+        ld8(base + ((long)y0 * w + x1) * C, p01);
+        ld8(base + ((long)y1 * w + x0) * C, p10);
+        ld8(base + ((long)y1 * w + x1) * C, p11);
+        float r[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k)
+            r[k] = ly0 * (lx0 * p00[k] + lx1 * p01[k]) + ly1 * (lx0 * p10[k] + lx1 * p11[k]);
+        if (tabx != nullptr) {
+            const int half = C / 2, c = c8 * 8;
+            float e[8];
+            ld8(c < half ? tabx + (long)X * half + c : taby + (long)Y * half + (c - half), e);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] += e[k];
+        }
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
             const unsigned short hb = f2bf(r[k]);
             hi[k] = (short)hb;
             lo[k] = (short)f2bf(r[k] - bf2f(hb));
         }
-        const long o = ((n * H + Y) * (long)W + X) * C + c4 * 4;
-        *reinterpret_cast<bf16x4*>(out_hi + o) = hi;
-        *reinterpret_cast<bf16x4*>(out_lo + o) = lo;
+        const long o = ((n * H + Y) * (long)W + X) * 2 * C + c8 * 8;
+        *reinterpret_cast<bf16x8*>(out + o) = hi;
+        *reinterpret_cast<bf16x8*>(out + o + C) = lo;
     }
 }
 
-int bilinear_ac_planes_launch(const float* in, unsigned short* out_hi, unsigned short* out_lo, int N, int h, int w, int H,
-                              int W, int C, hipStream_t st, const float* tabx, const float* taby) {
-    SKIMI_CHECK_ARG(C % 4 == 0, "bilinear resize needs C %% 4 == 0");
-    SKIMI_CHECK_ARG(tabx == nullptr || (taby != nullptr && C % 8 == 0), "fused uv pos embed needs both tables, C %% 8 == 0");
-    const long total = (long)N * H * W * (C / 4);
-    hipLaunchKernelGGL(bilinear_ac_planes_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, in, out_hi, out_lo, N, h,
-                       w, H, W, C, tabx, taby);
+int bilinear_ac_planes_launch(const float* in, unsigned short* out, int N, int h, int w, int H, int W, int C, hipStream_t st,
+                              const float* tabx, const float* taby) {
+    SKIMI_CHECK_ARG(C % 16 == 0, "bilinear resize into planes needs C %% 16 == 0");
+    SKIMI_CHECK_ARG(tabx == nullptr || taby != nullptr, "fused uv pos embed needs both tables");
+    const long total = (long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(bilinear_ac_planes_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, in, out, N, h, w, H, W,
+                       C, tabx, taby);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }
