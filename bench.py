@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="time steps of the clip per call (B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vp3d", action="store_true", help="skip the VideoPose3D lifter leg (profiling runs)")
     ap.add_argument("--cpu-views", type=int, default=2, help="views of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
@@ -149,7 +150,7 @@ def main():
                             "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(B),
                             "avg_launch_us": avg_s * 1e6, "launches": int(n.value),
                             "flops_per_launch": flops_per_launch}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_vp3d:
         line["vp3d"] = vp3d_leg(dev, cpu=not args.no_cpu_baseline)
     if rank == 0 and cpu_sd is not None:
         line["cpu_baseline"], line["parity_vs_cpu_oracle"] = cpu_baseline(cpu_sd, cfg, args.cpu_views, model, dev)

@@ -1,0 +1,46 @@
+"""profiles/r01_summary.md from a rocprofv3 kernel trace of bench.py and the bench line.
+usage: make_profile_summary.py <kernel_trace.csv> <bench_line.json> <steps in trace> <out.md>"""
+import csv, json, collections, sys
+trace, linef, NS, outp = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+rows = list(csv.DictReader(open(trace)))
+g = collections.defaultdict(lambda: [0, 0]); byk = collections.defaultdict(lambda: [0, 0]); tot = 0
+for r in rows:
+    n = r['Kernel_Name'].replace('void ', '').replace('skimi::', '').split('(')[0]
+    d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    k = (n, r['Grid_Size_X'], r['Workgroup_Size_X'])
+    g[k][0] += d; g[k][1] += 1; byk[n][0] += d; byk[n][1] += 1; tot += d
+line = json.load(open(linef))
+out = []
+out.append("# Round 1 — rocprofv3 --kernel-trace --stats of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vp3d`\n")
+out.append(f"MI355X (gfx950); {NS} steps in the trace (1 warm-up + {NS-1} timed); one step = 4 time steps x 8 views x 518x518 (the default `--batch 4`).")
+out.append(f"Total kernel time {tot/1e6:.1f} ms = {tot/NS/1e6:.1f} ms per step (includes the one-off weight upload / synthetic-weight kernels of the first step).\n")
+out.append("| kernel | ms / step | % | calls / step | avg us |\n|---|---:|---:|---:|---:|")
+for n, v in sorted(byk.items(), key=lambda kv: -kv[1][0])[:24]:
+    out.append(f"| `{n[:90]}` | {v[0]/NS/1e6:.2f} | {100*v[0]/tot:.1f} | {v[1]/NS:.0f} | {v[0]/v[1]/1e3:.1f} |")
+rf = line['roofline']
+out.append(f"\nUn-profiled bench line of the same build (`profiles/r01_bench_line.json`, full default run incl. the CPU legs):")
+out.append(f"- value {line['value']:.2f} frames/s, {line['ms_per_step']:.1f} ms/step (4 time steps), whole path {line['whole_path_tflops']:.0f} TFLOP/s")
+out.append(f"- roofline: {rf['kernel']}: {rf['achieved']:.0f} TFLOP/s = {100*rf['frac']:.1f}% of {rf['peak']:.0f} (avg launch {rf['avg_launch_us']:.0f} us over {rf['launches']} launches, HIP events on the launch stream inside bench.py); HBM traffic {rf['traffic']/1e6:.0f} MB per launch (`profiles/r01_attn_traffic.json`: FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes) against {4*10992*1024*2*4/1e6:.0f} MB algorithmic (q, k, v read once, o written once).  Run-to-run: fresh boxes differ by about +-2 % (clocks); 958-970 TFLOP/s were measured on others.")
+cb = line['cpu_baseline']
+out.append(f"- cpu_baseline: {cb['value']:.4f} frames/s on {cb['cores']} cores ({cb['sample']})")
+vp = line.get('vp3d')
+if vp:
+    out.append(f"- vp3d leg: {vp['clips_1']['us_per_call']:.0f} us per 243-frame clip at B=1 ({vp['clips_1']['achieved_GBps']:.0f} GB/s on the algorithmic bytes), {vp['clips_64']['us_per_call']/64:.1f} us per clip at B=64; CPU oracle {vp['cpu_oracle']['s_per_clip_with_flip_tta']*1e3:.1f} ms per clip on {vp['cpu_oracle']['cores']} cores (see `profiles/r01_vp3d_summary.md`)")
+out.append("\nPer-shape split of the attention kernel from the same trace (grouped by grid size):\n")
+out.append("| launches / step | grid (threads) | shape | avg us |\n|---:|---:|---|---:|")
+ga = None
+for k, v in sorted(g.items(), key=lambda kv: -kv[1][0]):
+    if 'attn' in k[0]:
+        wg = int(k[1]) // int(k[2])
+        if 'f32' in k[0]:
+            shape = "`attn_f32_kernel<128>`: camera-head trunk attention over the 8 camera tokens (fp32 kernel)"
+        elif wg == 2752:
+            shape = "global attention: batch 4, seq 8 x 1374 = 10992, 16 heads x 64"; ga = v
+        else:
+            shape = "frame / DINOv2 attention: batch 32, seq 1374, 16 heads x 64"
+        out.append(f"| {v[1]/NS:.0f} | {k[1]} = {wg} WG x {k[2]} | {shape} | {v[0]/v[1]/1e3:.1f} |")
+if ga:
+    out.append(f"\nThe {ga[0]/ga[1]/1e3:.0f} us of the global-attention launches under rocprofv3 against the {rf['avg_launch_us']:.0f} us that bench.py measures un-profiled (a different box; profiled passes also clock a few % lower, MI355X_MICROARCH.md cycle-constants note 2); {rf['flops_per_launch']/1e9:.1f} GFLOP per launch -> {rf['flops_per_launch']/(ga[0]/ga[1])/1e3:.0f} (profiled) / {rf['achieved']:.0f} (un-profiled) TFLOP/s.")
+out.append("\nGEMM shapes behind the `gemm256*` rows (M = 4 x 10992 = 43968 token rows): `gemm256_kernel<3,1>` qkv 1024->3072 (bias -> bf16), `gemm256pp_kernel<3>` fc1 1024->4096 (bias, GELU -> bf16), `gemm256pp_kernel<2>` proj 1024->1024 and fc2 4096->1024 (bias, LayerScale, fp32 residual).  `gemm_x3dma_kernel`, `gemm_kernel<...,3,float,float>` and `conv_direct_n32_kernel` are the fp32-accurate (bf16x3) convolutions of the depth and point DPT heads.")
+open(outp, 'w').write("\n".join(out) + "\n")
+print("\n".join(out)[:2500])
