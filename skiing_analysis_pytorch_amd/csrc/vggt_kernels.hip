@@ -91,15 +91,16 @@ __global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ 
                                                           int h, int w, int H, int W, int C,
                                                           const float* __restrict__ tabx,
                                                           const float* __restrict__ taby) {
+    // one output row (n, Y) per blockIdx.y; threads run over X * C/4: only 32-bit index math
     const int C4 = C / 4;
-    const long total = (long)N * H * W * C4;
+    const int rowlen = W * C4;
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c4 = (int)(i % C4);
-        const int X = (int)((i / C4) % W);
-        const int Y = (int)((i / ((long)C4 * W)) % H);
-        const long n = i / ((long)C4 * W * H);
+    const int Y = (int)(blockIdx.y % (unsigned)H);
+    const long n = blockIdx.y / (unsigned)H;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rowlen; i += gridDim.x * 256) {
+        const int X = i / C4;
+        const int c4 = i - X * C4;
         const float fy = sy * Y, fx = sx * X;
         const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
         const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
@@ -152,15 +153,16 @@ __global__ __launch_bounds__(256) void bilinear_ac_planes_kernel(const float* __
                                                                  int H, int W, int C, const float* __restrict__ tabx,
                                                                  const float* __restrict__ taby) {
     // 8 channels per thread: 16-B stores into each plane
+    // one output row (n, Y) per blockIdx.y; threads run over X * C/8: only 32-bit index math
     const int C8 = C / 8;
-    const long total = (long)N * H * W * C8;
+    const int rowlen = W * C8;
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c8 = (int)(i % C8);
-        const int X = (int)((i / C8) % W);
-        const int Y = (int)((i / ((long)C8 * W)) % H);
-        const long n = i / ((long)C8 * W * H);
+    const int Y = (int)(blockIdx.y % (unsigned)H);
+    const long n = blockIdx.y / (unsigned)H;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rowlen; i += gridDim.x * 256) {
+        const int X = i / C8;
+        const int c8 = i - X * C8;
         const float fy = sy * Y, fx = sx * X;
         const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
         const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
@@ -204,9 +206,10 @@ int bilinear_ac_planes_launch(const float* in, unsigned short* out, int N, int h
                               const float* tabx, const float* taby) {
     SKIMI_CHECK_ARG(C % 16 == 0, "bilinear resize into planes needs C %% 16 == 0");
     SKIMI_CHECK_ARG(tabx == nullptr || taby != nullptr, "fused uv pos embed needs both tables");
-    const long total = (long)N * H * W * (C / 8);
-    hipLaunchKernelGGL(bilinear_ac_planes_kernel, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, in, out, N, h, w, H, W,
-                       C, tabx, taby);
+    SKIMI_CHECK_ARG((long)N * H < 65536, "bilinear resize into planes: N * H must be < 65536");
+    const int rowlen = W * (C / 8);
+    hipLaunchKernelGGL(bilinear_ac_planes_kernel, dim3((unsigned)cdiv(rowlen, 256), (unsigned)(N * H)), dim3(256), 0, st, in, out, N,
+                       h, w, H, W, C, tabx, taby);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }
@@ -215,13 +218,14 @@ int bilinear_ac_launch(const void* in, void* out, int dtype, int N, int h, int w
                        hipStream_t st, const float* tabx, const float* taby) {
     SKIMI_CHECK_ARG(C % 4 == 0, "bilinear resize needs C %% 4 == 0");
     SKIMI_CHECK_ARG(tabx == nullptr || (taby != nullptr && C % 8 == 0), "fused uv pos embed needs both tables, C %% 8 == 0");
-    const long total = (long)N * H * W * (C / 4);
+    SKIMI_CHECK_ARG((long)N * H < 65536, "bilinear resize: N * H must be < 65536");
+    const dim3 grid((unsigned)cdiv((long)W * (C / 4), 256), (unsigned)(N * H));
     if (dtype == SKIMI_F32)
-        hipLaunchKernelGGL(bilinear_ac_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st,
-                           (const float*)in, (float*)out, N, h, w, H, W, C, tabx, taby);
+        hipLaunchKernelGGL(bilinear_ac_kernel<float>, grid, dim3(256), 0, st, (const float*)in, (float*)out, N, h, w, H, W, C,
+                           tabx, taby);
     else
-        hipLaunchKernelGGL(bilinear_ac_kernel<unsigned short>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st,
-                           (const unsigned short*)in, (unsigned short*)out, N, h, w, H, W, C, tabx, taby);
+        hipLaunchKernelGGL(bilinear_ac_kernel<unsigned short>, grid, dim3(256), 0, st, (const unsigned short*)in,
+                           (unsigned short*)out, N, h, w, H, W, C, tabx, taby);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }
