@@ -1,10 +1,12 @@
-// bf16 flash attention for head_dim 64 on gfx950 MFMA (v_mfma_f32_32x32x16_bf16), fp32 softmax.
-// The MFMA-roofline kernel of the path: frame attention (batch = S frames, seq 1374) and global
-// attention (batch = 1, seq = S*1374) of vggt/vggt/models/aggregator.py:260-305 via
-// F.scaled_dot_product_attention (vggt/vggt/layers/attention.py:60-61), and the 24 DINOv2 blocks.
+// bf16 flash attention for head_dim 64 on gfx950 MFMA (v_mfma_f32_32x32x16_bf16), fp32 softmax:
+// frame attention (batch = S frames, seq 1374) and global attention (batch = B, seq = S*1374) of
+// vggt/vggt/models/aggregator.py:260-305 via F.scaled_dot_product_attention
+// (vggt/vggt/layers/attention.py:60-61), and the 24 DINOv2 blocks.
 //
-// Per workgroup: 4 waves x 32 queries; K/V tiles of 64 keys double-buffered in LDS, staged
-// global -> VGPR -> LDS (issue before the MFMA phase, write after it), one barrier per tile.
+// This file: the launcher (attention_bf16_launch picks the kernel: the 64-query-per-wave kernel of
+// attention_q64.hip by default) and the FIRST kernel, kept for A/B timing (SKIMI_ATTN_Q64=0):
+// per workgroup 4 waves x 32 queries; K/V tiles of 64 keys double-buffered in LDS by LDS-DMA, one
+// barrier per tile, row sums on the matrix pipe (ones-operand MFMAs).
 // Products are "swapped" so each softmax row is lane-local:
 //   S^T[key, q] = K Q^T   A = K from LDS (ds_read_b128, XOR-swizzled rows), B = Q from registers
 //   O^T[d, q]  += V^T P^T A = V^T from LDS via ds_read_b64_tr_b16 (hardware transpose of a

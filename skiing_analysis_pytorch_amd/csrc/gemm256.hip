@@ -9,8 +9,12 @@
 //   * a wave-instruction of global_load_lds writes 1 KiB = 8 rows x 128 B linearly, so the
 //     bank-conflict swizzle (16-B chunk ^= (row>>1)&7) is applied to the per-lane SOURCE
 //     address and again on the ds_read_b128 (both sides or neither);
-//   * two-phase loop: issue tile t+1's DMA, MFMA tile t, vmcnt(0) + barrier;
-//   * epilogue through per-wave LDS slabs -> row-contiguous 16-B stores (shared with gemm.hip).
+//   * two main loops: the two-phase loop (issue tile t+1's DMA, MFMA tile t, vmcnt(0) + barrier;
+//     192- or 256-row tiles) and the ping-pong loop for 256-row tiles (counted vmcnt, raw barriers;
+//     see gemm256pp_kernel); gemm256_launch picks by the CU-rounds a shape wastes;
+//   * tiles are walked in 8 x 4 patches per XCD (tile_coords256);
+//   * compile-time epilogues through per-wave LDS slabs -> row-contiguous 16-B stores, branch-free
+//     on interior tiles (epilogue256).
 #include <stdlib.h>
 
 #include "common.h"
