@@ -157,6 +157,21 @@ int skimi_conv3x3_n32(const void* in_hi, const void* in_lo, const void* packed_w
                       int32_t F, int32_t H, int32_t W, int32_t C, int32_t relu, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Image preprocessing on the device (vggt/load.py:38-183)                    */
+/* ------------------------------------------------------------------------- */
+/* One separable pass of Pillow's 8-bit resampler (what Image.resize(..., BICUBIC) runs on the host
+ * in the reference): element (o, n, i) of `in` lives at (o * n_in + n) * inner + i; `kk` is
+ * [n_out, ksize] int32 22-bit fixed-point coefficients, `bounds` [n_out, 2] = (first input index,
+ * tap count), both built on the host as Pillow builds them (skiing_analysis_pytorch_amd/preprocess.py).
+ * Horizontal pass of an HWC image: outer = H, inner = C; vertical pass: outer = 1, inner = W * C. */
+int skimi_resample_u8(const uint8_t* in, uint8_t* out, int64_t outer, int32_t n_in, int32_t n_out, int64_t inner,
+                      const int32_t* kk, const int32_t* bounds, int32_t ksize, void* stream);
+/* uint8 HWC (3 channels) -> fp32 [3, OH, OW] = value / 255; output pixel (y, x) reads input pixel
+ * (y + y_off, x + x_off), pixels outside the input are `fill` (centre crop / white padding). */
+int skimi_u8_hwc_to_f32_chw(const uint8_t* in, int32_t H, int32_t W, float* out, int32_t OH, int32_t OW, int32_t y_off,
+                            int32_t x_off, float fill, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Row-wise ops on token streams                                              */
 /* ------------------------------------------------------------------------- */
 /* LayerNorm over the last dim C of x[rows, C] (optionally the concatenation of two

@@ -100,6 +100,16 @@ int skimi_gemm(const skimi_gemm_desc* d, void* stream) {
                          d->force_splitk);
 }
 
+int skimi_resample_u8(const uint8_t* in, uint8_t* out, int64_t outer, int32_t n_in, int32_t n_out, int64_t inner,
+                      const int32_t* kk, const int32_t* bounds, int32_t ksize, void* stream) {
+    return resample_u8_launch(in, out, outer, n_in, n_out, inner, kk, bounds, ksize, (hipStream_t)stream);
+}
+
+int skimi_u8_hwc_to_f32_chw(const uint8_t* in, int32_t H, int32_t W, float* out, int32_t OH, int32_t OW, int32_t y_off,
+                            int32_t x_off, float fill, void* stream) {
+    return u8_hwc_to_f32_chw_launch(in, H, W, out, OH, OW, y_off, x_off, fill, (hipStream_t)stream);
+}
+
 int skimi_conv3x3_n32_pack(const float* w, void* packed, int32_t C, void* stream) {
     SKIMI_CHECK_ARG(w && packed && C > 0, "skimi_conv3x3_n32_pack: bad arguments");
     return conv_direct_pack_launch(w, (unsigned short*)packed, C, (hipStream_t)stream);

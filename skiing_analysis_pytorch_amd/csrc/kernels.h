@@ -31,6 +31,11 @@ struct AttnArgs {
 };
 int attention_f32_launch(const AttnArgs& a, hipStream_t st);
 int attention_bf16_launch(const AttnArgs& a, hipStream_t st);
+// preprocess.hip: Pillow-exact separable uint8 resample pass, uint8 HWC -> fp32 CHW / 255 with crop / pad
+int resample_u8_launch(const unsigned char* in, unsigned char* out, long outer, int n_in, int n_out, long inner,
+                       const int* kk, const int* bounds, int ksize, hipStream_t st);
+int u8_hwc_to_f32_chw_launch(const unsigned char* in, int H, int W, float* out, int OH, int OW, int y_off, int x_off,
+                             float fill, hipStream_t st);
 // conv_direct.hip: 3x3, Cin % 32 == 0 -> 32 channels, pad 1, fp32-accurate, on bf16 hi/lo planes
 int conv_direct_pack_launch(const float* w, unsigned short* out, int Cin, hipStream_t st);
 int conv_direct_n32_launch(const unsigned short* in_hi, const unsigned short* in_lo, const unsigned short* w_packed,

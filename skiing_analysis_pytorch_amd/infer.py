@@ -26,10 +26,15 @@ from .vggt import VGGT
 from .weights import VGGTConfig
 
 
-def load_and_preprocess_images(image_list: Sequence, mode: str = "crop") -> torch.Tensor:
+def load_and_preprocess_images(image_list: Sequence, mode: str = "crop", device=None) -> torch.Tensor:
     """vggt/load.py:38-183.  image_list: HWC uint8 tensors / arrays.  Width -> 518 (bicubic, PIL),
     height -> round(h*518/w/14)*14, centre-crop heights > 518 ("crop") or pad to 518x518 with
-    white ("pad").  Returns [N, 3, H, W] float32 in [0, 1] on the host."""
+    white ("pad").  Returns [N, 3, H, W] float32 in [0, 1] on the host (as the reference), or, with
+    `device="cuda"`, computed on and left in GPU memory (preprocess.py: Pillow's resampler as HIP
+    kernels, bit-identical to the host path)."""
+    if device is not None and torch.device(device).type == "cuda":
+        from .preprocess import load_and_preprocess_images_device
+        return load_and_preprocess_images_device(image_list, mode, device)
     from PIL import Image
 
     if len(image_list) == 0:

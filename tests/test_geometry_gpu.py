@@ -77,3 +77,24 @@ def test_multi_view_clip_pipeline(golden_dir):
                                             E[0, :, :3, 3].numpy().astype(np.float64), kps[0].cpu().numpy().astype(np.float64))
     got = res["joints3d"][0].cpu().numpy()
     assert np.abs(got - ref).max() / (np.abs(ref).max() + 1) < 1e-2
+
+
+@pytest.mark.parametrize("mode", ["crop", "pad"])
+def test_device_preprocessing_bit_identical_to_host_path(mode):
+    """load_and_preprocess_images(device="cuda") (Pillow's resampler as HIP kernels) against the host
+    path (PIL, as the reference): landscape, portrait (crop mode centre-crops the 924-row result),
+    already-518-wide and tiny frames, mixed shapes in one batch (white padding to the largest)."""
+    rng = np.random.default_rng(7)
+    sets = [
+        [rng.integers(0, 256, (135, 240, 3), dtype=np.uint8) for _ in range(3)],          # 16:9 -> 518 x 294
+        [rng.integers(0, 256, (240, 135, 3), dtype=np.uint8)],                            # portrait
+        [rng.integers(0, 256, (200, 518, 3), dtype=np.uint8)],                            # width already 518
+        [rng.integers(0, 256, (135, 240, 3), dtype=np.uint8), rng.integers(0, 256, (96, 96, 3), dtype=np.uint8)],
+    ]
+    for frames in sets:
+        host = infer.load_and_preprocess_images(frames, mode)
+        dev = infer.load_and_preprocess_images(frames, mode, device="cuda")
+        assert dev.is_cuda and dev.shape == host.shape and dev.dtype == torch.float32
+        assert torch.equal(dev.cpu(), host)
+    with pytest.raises(ValueError):
+        infer.load_and_preprocess_images([], mode, device="cuda")
