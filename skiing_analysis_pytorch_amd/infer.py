@@ -121,7 +121,12 @@ class CameraHead:
     @torch.no_grad()
     def run_vggt(self, images: List[torch.Tensor], to_numpy: bool = True):
         """infer.py:71-105.  Returns (out dict, H, W).  With to_numpy=False everything stays in HBM."""
-        imgs = load_and_preprocess_images(images).to(self.device)
+        # RGB uint8 frames are resized on the GPU (bit-identical to the PIL path, preprocess.py);
+        # anything else (RGBA, other dtypes) takes the reference's host path
+        def _rgb8(im):
+            return getattr(im, "dtype", None) in (torch.uint8, np.uint8) and getattr(im, "ndim", 0) == 3 and im.shape[2] == 3
+        on_dev = all(_rgb8(im) for im in images)
+        imgs = load_and_preprocess_images(images, device=self.device if on_dev else None).to(self.device)
         preds = self.vggt(imgs)
         H, W = imgs.shape[-2:]
         E, K = geometry.pose_encoding_to_extri_intri(preds["pose_enc"], (H, W))
