@@ -124,3 +124,64 @@ def test_pt_clip_loader_roundtrip(tmp_path):
         formats.load_info(tmp_path / "bad.pt")
     out = formats.save_pose_npy(tmp_path / "pose.npy", np.zeros((T, 17, 3)))
     assert np.load(out).shape == (T, 17, 3)
+
+
+def _same(a, b, tol=1e-12):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_allclose(np.nan_to_num(a), np.nan_to_num(b), rtol=0, atol=tol)
+
+
+def test_kabsch_alignment_matches_reference(golden_dir):
+    """fuse/main_raw.py: incl. a reflected frame (det < 0 branch) and a frame with < 3 common joints."""
+    g = np.load(golden_dir / "fuse_align.npz")
+    L, R = g["kab_left"], g["kab_right"]
+    for t in range(L.shape[0]):
+        out = fuse.align_right_to_left(L[t], R[t])
+        # the reference drops joints whose aligned value is not finite; arrays keep them as NaN rows
+        _same(np.where(np.isfinite(out).all(1, keepdims=True), out, np.nan), g["kab_aligned"][t])
+        both = np.isfinite(L[t]).all(1) & np.isfinite(R[t]).all(1)
+        if both.sum() >= 3:
+            Rm, tv = fuse.kabsch_rigid_align(R[t][both], L[t][both])
+            _same(Rm, g["kab_R"][t]); _same(tv, g["kab_t"][t])
+            assert abs(np.linalg.det(Rm) - 1.0) < 1e-9
+
+
+def test_confidences_match_reference(golden_dir):
+    g = np.load(golden_dir / "fuse_align.npz")
+    for t in range(g["wp_X"].shape[0]):
+        conf, err, uhat, prm = fuse.weakpersp_reproj_confidence(g["wp_X"][t], g["wp_U"][t], sigma_px=12.0)
+        _same(conf, g["wp_conf"][t]); _same(err, g["wp_err"][t], 1e-9); _same(uhat, g["wp_uhat"][t], 1e-9)
+        _same(prm["M"], g["wp_M"][t]); _same(prm["t"], g["wp_t"][t], 1e-9)
+        assert abs(prm["s"] - g["wp_s"][t]) < 1e-9
+    with pytest.raises(ValueError):
+        fuse.weakpersp_reproj_confidence(g["wp_X"][0][:5], g["wp_U"][0][:5])
+    kw = dict(root_idx=0, left_hip_idx=11, right_hip_idx=12, left_shoulder_idx=5, right_shoulder_idx=6)
+    i = 0
+    for t in range(g["cv_A"].shape[0]):
+        for mode in ("hip", "torso"):
+            conf, dist, A, B, _ = fuse.crossview_consistency_confidence(g["cv_A"][t], g["cv_B"][t], sigma_3d=0.3,
+                                                                        scale_mode=mode, **kw)
+            _same(conf, g["cv_conf"][i]); _same(dist, g["cv_dist"][i]); _same(A, g["cv_Ac"][i]); _same(B, g["cv_Bc"][i])
+            i += 1
+    with pytest.raises(ValueError):
+        fuse.canonicalize_pose_3d(g["cv_A"][0], scale_mode="bone", **kw)
+
+
+def test_h36m_left_right_fusion_matches_reference(golden_dir):
+    """VideoPose3D/fuse/fuse.py incl. the transposed-rotation quirk of estimate_rigid_umeyama, missing joints on
+    either / both sides, mirrored right view with scale, per-frame weights, single-pose input."""
+    g = np.load(golden_dir / "fuse_align.npz")
+    L, R = g["h36_L"], g["h36_R"]
+    f0, d0 = fuse.fuse_pose_no_extrinsics_h36m(L, R, tau=0.08)
+    _same(f0, g["h36_f0"])
+    _same([d["gain"] for d in d0["per_frame"]], g["h36_gain0"])
+    _same(np.stack([d["R"] for d in d0["per_frame"]]), g["h36_R0"])
+    assert list(d0["bad_frames"]) == list(g["h36_bad0"])
+    _same(d0["mean_gain"], g["h36_mean_gain0"])
+    f1, d1 = fuse.fuse_pose_no_extrinsics_h36m(L, R, tau=0.3, allow_scale=True, mirror_right_x=True, wL=g["h36_wl"], wR=g["h36_wr"])
+    _same(f1, g["h36_f1"]); _same([d["s"] for d in d1["per_frame"]], g["h36_s1"]); _same([d["gain"] for d in d1["per_frame"]], g["h36_gain1"])
+    f2, d2 = fuse.fuse_pose_no_extrinsics_h36m(L[0], R[0], tau=0.5, wL=g["h36_wl"][0], wR=g["h36_wr"][0], return_diagnostics=False)
+    assert d2 is None and f2.shape == (17, 3)
+    _same(f2, g["h36_f2"])

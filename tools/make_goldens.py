@@ -229,6 +229,96 @@ def gen_fuse():
 GENERATORS["fuse"] = gen_fuse
 
 
+def gen_fuse_align():
+    """The rest of SURVEY f2: fuse/main_raw.py (Kabsch right->left alignment), fuse/confidence.py
+    (weak-perspective reprojection and cross-view consistency confidences) and
+    VideoPose3D/fuse/fuse.py (H36M-17 left/right fusion without extrinsics) on synthetic poses with
+    missing joints.  The reference functions print diagnostics; stdout is silenced."""
+    import contextlib, io
+    from fuse.main_raw import _kabsch_rigid_align, _align_right_to_left
+    from fuse.confidence import weakpersp_reproj_confidence, crossview_consistency_confidence
+    from VideoPose3D.fuse.fuse import fuse_pose_no_extrinsics_h36m
+
+    rng = np.random.default_rng(1)
+    out = {}
+    # --- Kabsch: 17 COCO joints, right view = rotated + translated left view + noise, NaNs on both sides
+    ids = list(range(17))
+    J = len(ids)
+    A = rng.normal(size=(6, J, 3))
+    ang = rng.normal(size=(6, 3))
+    Rm = []
+    for a in ang:
+        cx, sx, cy, sy, cz, sz = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
+        Rm.append(np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+                  @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    Rm = np.stack(Rm)
+    Bv = np.einsum("tij,tkj->tki", Rm, A) + rng.normal(size=(6, 1, 3)) + rng.normal(scale=0.01, size=(6, J, 3))
+    Bv[5] = -Bv[5]                                   # a reflected frame: exercises the det < 0 branch
+    missA = rng.random((6, J)) < 0.15
+    missB = rng.random((6, J)) < 0.15
+    missA[4] = True; missA[4, :2] = False            # fewer than 3 common joints -> right view returned as is
+    A_n = np.where(missA[..., None], np.nan, A)
+    B_n = np.where(missB[..., None], np.nan, Bv)
+    aligned = np.full((6, J, 3), np.nan)
+    rots, trs = [], []
+    for t in range(6):
+        dl = {j: A_n[t, j] for j in ids if not missA[t, j]}
+        dr = {j: B_n[t, j] for j in ids if not missB[t, j]}
+        res = _align_right_to_left(dl, dr, ids)
+        for j in ids:
+            if j in res:
+                aligned[t, j] = res[j]
+        v = ~missA[t] & ~missB[t]
+        if v.sum() >= 3:
+            r, tr = _kabsch_rigid_align(B_n[t][v], A_n[t][v])
+        else:
+            r, tr = np.full((3, 3), np.nan), np.full(3, np.nan)
+        rots.append(r); trs.append(tr)
+    out.update(kab_left=A_n, kab_right=B_n, kab_aligned=aligned, kab_R=np.stack(rots), kab_t=np.stack(trs))
+    # --- confidences (dict inputs in the reference: every joint present, NaN allowed in the values)
+    X3 = rng.normal(size=(4, J, 3))
+    M = np.linalg.qr(rng.normal(size=(3, 3)))[0][:, :2]
+    U2 = 180.0 * (X3 @ M) + np.array([320.0, 240.0]) + rng.normal(scale=4.0, size=(4, J, 2))
+    X3[1, 3] = np.nan; U2[2, 5] = np.nan
+    conf, err, uhat, ps, pM, pt = [], [], [], [], [], []
+    for t in range(4):
+        c, e, uh, prm = weakpersp_reproj_confidence({j: X3[t, j] for j in ids}, {j: U2[t, j] for j in ids}, sigma_px=12.0)
+        conf.append(c); err.append(e); uhat.append(uh); ps.append(prm["s"]); pM.append(prm["M"]); pt.append(prm["t"])
+    out.update(wp_X=X3, wp_U=U2, wp_conf=np.stack(conf), wp_err=np.stack(err), wp_uhat=np.stack(uhat), wp_s=np.array(ps),
+               wp_M=np.stack(pM), wp_t=np.stack(pt))
+    Xa = rng.normal(size=(4, J, 3))
+    Xb = np.einsum("ij,tkj->tki", Rm[0], Xa) * 1.7 + rng.normal(scale=0.05, size=(4, J, 3))
+    Xa[2, 9] = np.nan
+    Xb[3, 11] = np.nan                                # a key joint missing -> everything NaN / conf 0
+    kw = dict(root_idx=0, left_hip_idx=11, right_hip_idx=12, left_shoulder_idx=5, right_shoulder_idx=6)
+    cc, dd, xa, xb = [], [], [], []
+    for t in range(4):
+        for mode in ("hip", "torso"):
+            c, d, a_c, b_c, _ = crossview_consistency_confidence({j: Xa[t, j] for j in ids}, {j: Xb[t, j] for j in ids},
+                                                                 sigma_3d=0.3, scale_mode=mode, **kw)
+            cc.append(c); dd.append(d); xa.append(a_c); xb.append(b_c)
+    out.update(cv_A=Xa, cv_B=Xb, cv_conf=np.stack(cc), cv_dist=np.stack(dd), cv_Ac=np.stack(xa), cv_Bc=np.stack(xb))
+    # --- VideoPose3D left/right fusion (H36M-17)
+    T = 12
+    Lh = rng.normal(size=(T, 17, 3))
+    Rh = np.einsum("ij,tkj->tki", Rm[1], Lh) + rng.normal(scale=0.04, size=(T, 17, 3)) + rng.normal(size=(T, 1, 3))
+    Lh[3, 13] = np.nan; Rh[4, 16] = np.nan; Lh[5, 2] = np.nan; Rh[5, 2] = np.nan
+    wl, wr = rng.random((T, 17)), rng.random((T, 17))
+    with contextlib.redirect_stdout(io.StringIO()):
+        f0, d0 = fuse_pose_no_extrinsics_h36m(Lh, Rh, tau=0.08)
+        f1, d1 = fuse_pose_no_extrinsics_h36m(Lh, Rh, tau=0.3, allow_scale=True, mirror_right_x=True, wL=wl, wR=wr)
+        f2, _ = fuse_pose_no_extrinsics_h36m(Lh[0], Rh[0], tau=0.5, wL=wl[0], wR=wr[0], return_diagnostics=False)
+    out.update(h36_L=Lh, h36_R=Rh, h36_wl=wl, h36_wr=wr, h36_f0=f0, h36_f1=f1, h36_f2=f2,
+               h36_gain0=np.array([d["gain"] for d in d0["per_frame"]]), h36_gain1=np.array([d["gain"] for d in d1["per_frame"]]),
+               h36_R0=np.stack([d["R"] for d in d0["per_frame"]]), h36_s1=np.array([d["s"] for d in d1["per_frame"]]),
+               h36_bad0=np.array(d0["bad_frames"], dtype=np.int64), h36_mean_gain0=np.array(d0["mean_gain"]))
+    np.savez_compressed(GOLD / "fuse_align.npz", **out)
+    print("wrote fuse_align.npz")
+
+
+GENERATORS["fuse_align"] = gen_fuse_align
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENERATORS)
     for w in which:
