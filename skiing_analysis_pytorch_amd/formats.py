@@ -91,3 +91,45 @@ def save_pose_npy(path, prediction: np.ndarray) -> Path:
     p.parent.mkdir(parents=True, exist_ok=True)
     np.save(p, np.asarray(prediction, dtype=np.float32))
     return p if p.suffix == ".npy" else p.with_suffix(p.suffix + ".npy")
+
+
+def save_3d_joints(fused_joints_3d: np.ndarray, left_joints_3d: np.ndarray, right_joints_3d: np.ndarray, save_path,
+                   fmt: str = "npy") -> Path:
+    """VideoPose3D/save.py:31-61: one `.npy` holding a dict of nested lists
+    {"fused_joints_3d", "left_joints_3d", "right_joints_3d"} (an object array, i.e. a pickle: readers use
+    `np.load(path, allow_pickle=True).item()`).  Any other `fmt` raises ValueError like the reference."""
+    if fmt != "npy":
+        raise ValueError(f"Unsupported format: {fmt}")
+    p = Path(save_path)
+    p.parent.mkdir(parents=True, exist_ok=True)
+    payload = {
+        "fused_joints_3d": np.asarray(fused_joints_3d).tolist(),
+        "left_joints_3d": np.asarray(left_joints_3d).tolist(),
+        "right_joints_3d": np.asarray(right_joints_3d).tolist(),
+    }
+    np.save(p, payload)
+    return p if p.suffix == ".npy" else p.with_suffix(p.suffix + ".npy")
+
+
+def load_3d_joints(path) -> dict:
+    """Reader of `save_3d_joints` files written by THIS package (unpickles: never point it at a file of
+    unknown origin).  -> dict of float64 arrays."""
+    d = np.load(Path(path), allow_pickle=True).item()
+    return {k: np.asarray(d[k], dtype=np.float64) for k in ("fused_joints_3d", "left_joints_3d", "right_joints_3d")}
+
+
+def save_predictions_npz(outdir, preds: dict) -> Path:
+    """vggt/save.py:52-56: `<outdir>/predictions.npz` = np.savez of every array of the prediction dict
+    (device tensors are brought to the host; None entries, e.g. pose_enc_list, are skipped as np.savez
+    cannot hold them without pickling)."""
+    out = Path(outdir)
+    out.mkdir(parents=True, exist_ok=True)
+    arrays = {}
+    for k, v in preds.items():
+        if v is None:
+            continue
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        arrays[k] = np.asarray(v)
+    np.savez(out / "predictions.npz", **arrays)
+    return out / "predictions.npz"

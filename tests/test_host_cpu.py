@@ -185,3 +185,23 @@ def test_h36m_left_right_fusion_matches_reference(golden_dir):
     f2, d2 = fuse.fuse_pose_no_extrinsics_h36m(L[0], R[0], tau=0.5, wL=g["h36_wl"][0], wR=g["h36_wr"][0], return_diagnostics=False)
     assert d2 is None and f2.shape == (17, 3)
     _same(f2, g["h36_f2"])
+
+
+def test_joint_and_prediction_writers(tmp_path):
+    """f3: VideoPose3D/save.py dict-npy of fused / left / right joints and vggt/save.py predictions.npz."""
+    from skiing_analysis_pytorch_amd import formats
+    rng = np.random.default_rng(3)
+    f, l, r = rng.normal(size=(5, 17, 3)), rng.normal(size=(5, 17, 3)), rng.normal(size=(5, 17, 3))
+    p = formats.save_3d_joints(f, l, r, tmp_path / "person" / "clip_3d")
+    assert p.suffix == ".npy" and p.exists()
+    raw = np.load(p, allow_pickle=True).item()            # what the reference's consumers do
+    assert set(raw) == {"fused_joints_3d", "left_joints_3d", "right_joints_3d"} and isinstance(raw["fused_joints_3d"], list)
+    back = formats.load_3d_joints(p)
+    np.testing.assert_array_equal(back["fused_joints_3d"], f)
+    np.testing.assert_array_equal(back["right_joints_3d"], r)
+    with pytest.raises(ValueError):
+        formats.save_3d_joints(f, l, r, tmp_path / "x", fmt="csv")
+    preds = {"depth": torch.ones(1, 2, 4, 4, 1), "pose_enc": np.zeros((1, 2, 9), np.float32), "pose_enc_list": None}
+    q = formats.save_predictions_npz(tmp_path / "out", preds)
+    z = np.load(q)
+    assert sorted(z.files) == ["depth", "pose_enc"] and z["depth"].shape == (1, 2, 4, 4, 1)
