@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     // ---- per-thread staging coordinates ----
     int a_r[A_IT], a_c[A_IT];
     bool a_ok[A_IT];
-    long a_base[A_IT];            // plain: row base (elements); conv: image index
+    long a_base[A_IT];            // plain: row base (elements); conv: window's top-left pixel + chunk (elements)
     int a_iy0[A_IT], a_ix0[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -134,9 +134,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             int rem = m - img * ohw;
             int oy = rem / p.OW;
             int ox = rem - oy * p.OW;
-            a_base[i] = img;
             a_iy0[i] = oy * p.stride - p.pad;
             a_ix0[i] = ox * p.stride - p.pad;
+            // window's top-left pixel + this lane's chunk; the tap / channel part is wave-uniform (per K-tile)
+            a_base[i] = (((long)img * p.cH + a_iy0[i]) * p.cW + a_ix0[i]) * p.lda + a_c[i] * 8;
         }
     }
     int w_r[W_IT], w_c[W_IT];
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             tap_dx = kx * p.dil;                                                                        \
         }                                                                                               \
         unsigned okm = 0;                                                                               \
+        const long tap_off = ((long)tap_dy * p.cW + tap_dx) * p.lda + cin0;  /* wave-uniform */         \
         _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                              \
             const int kk = k0 + a_c[i] * 8;                                                             \
             bool ok = a_ok[i] && kk < ke;                                                               \
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             } else {                                                                                    \
                 int iy = a_iy0[i] + tap_dy, ix = a_ix0[i] + tap_dx;                                     \
                 ok = ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;                                \
-                off = ((a_base[i] * p.cH + iy) * p.cW + ix) * p.lda + cin0 + a_c[i] * 8;                \
+                off = a_base[i] + tap_off;                                                              \
             }                                                                                           \
             stage_load(sa[SET][i], reinterpret_cast<const TA*>(p.A) + (ok ? off : 0));                  \
             okm |= ok ? (1u << i) : 0u;                                                                 \

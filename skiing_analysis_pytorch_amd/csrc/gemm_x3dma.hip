@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3dma_kernel(const GemmArgs p, co
     // ---- staging coordinates: lane -> (row = lane>>2 of the 16-row group, LDS chunk = lane&3) ----
     const int srow = lane >> 2, schunk = lane & 3;
     int a_row[A_INS];          // tile row
-    long a_base[A_INS];        // plain: element offset of the row; conv: image index
+    long a_base[A_INS];        // element offset of the row (plain) / of the window's top-left pixel (conv), + chunk
     int a_iy0[A_INS], a_ix0[A_INS];
     int a_c[A_INS];            // source chunk (swizzled)
 #pragma unroll
@@ -109,9 +109,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x3dma_kernel(const GemmArgs p, co
             const int img = m / ohw;
             const int rem = m - img * ohw;
             const int oy = rem / p.OW;
-            a_base[j] = img;
             a_iy0[j] = oy * p.stride - p.pad;
             a_ix0[j] = (rem - oy * p.OW) * p.stride - p.pad;
+            // the tap and channel-slice part of the address is wave-uniform and added per K-tile
+            a_base[j] = (((long)img * p.cH + a_iy0[j]) * p.cW + a_ix0[j]) * p.lda + a_c[j] * 8;
         }
     }
     long w_base[W_INS];
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3dma_kernel(const GemmArgs p, co
             tap_dx = (tap - ky * p.KW) * p.dil;
         }
         char* base = smem + buf * BUF;
+        const long tap_off = ((long)tap_dy * p.cW + tap_dx) * p.lda + cin0;   // wave-uniform (scalar unit)
 #pragma unroll
         for (int j = 0; j < A_INS; ++j) {
             const int kk = k0 + a_c[j] * 8;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void gemm_x3dma_kernel(const GemmArgs p, co
             } else {
                 const int iy = a_iy0[j] + tap_dy, ix = a_ix0[j] + tap_dx;
                 ok = ok && iy >= 0 && iy < p.cH && ix >= 0 && ix < p.cW;
-                off = ((a_base[j] * p.cH + iy) * p.cW + ix) * p.lda + cin0 + a_c[j] * 8;
+                off = a_base[j] + tap_off;
             }
             const unsigned short* sh = ok ? pl.a_hi + off : pl.zero;
             const unsigned short* sl = ok ? pl.a_lo + off : pl.zero;
