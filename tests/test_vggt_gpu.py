@@ -109,23 +109,25 @@ def test_vggt_track_head_matches_reference(golden_dir):
     assert torch.allclose(out["track"][0, 0].cpu(), torch.from_numpy(g["query_points"]), atol=1e-5)
 
 
-def test_vggt_fullsize_fp32_mode_vs_oracle():
-    """VGGT-1B (the reference's VGGT() sizes), 2 views x 518x518, synthetic weights generated on
-    the device and shared with the CPU oracle: the fp32-accurate mode must meet the 1e-3 bar at
-    FULL size too (the goldens cover the tiny configs)."""
+@pytest.mark.parametrize("H,W,head", [(518, 518, "depth"), (294, 518, "point")])
+def test_vggt_fullsize_fp32_mode_vs_oracle(H, W, head):
+    """VGGT-1B (the reference's VGGT() sizes), 2 views, synthetic weights generated on the device and
+    shared with the CPU oracle: the fp32-accurate mode must meet the 1e-3 bar at FULL size too (the
+    goldens cover the tiny configs) -- square frames with the depth head, and the 16:9 footage shape
+    294 x 518 (resized pos_embed, ragged 16 x 16 tiles of the direct output conv) with the point head."""
     import os
 
     from skiing_analysis_pytorch_amd import weights as Wt
 
-    cfg = Wt.VGGTConfig(enable_point=False, enable_track=False)
+    cfg = Wt.VGGTConfig(enable_depth=(head == "depth"), enable_point=(head == "point"), enable_track=False)
     sd = Wt.make_vggt_state_dict(cfg, seed=3, device="cuda")
     m = vggt.VGGT(config=cfg, prec=PREC_BF16X3, head_prec=PREC_BF16X3)
     m.load_state_dict(sd)
     cpu_sd = {k: v.cpu() for k, v in sd.items()}
     del sd
     torch.cuda.empty_cache()
-    img = torch.rand((1, 2, 3, 518, 518), generator=torch.Generator().manual_seed(11))
-    out = m(img.cuda(), want={"camera", "depth"})
+    img = torch.rand((1, 2, 3, H, W), generator=torch.Generator().manual_seed(11))
+    out = m(img.cuda(), want={"camera", head})
     try:
         torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
     except AttributeError:
@@ -133,7 +135,9 @@ def test_vggt_fullsize_fp32_mode_vs_oracle():
     with torch.no_grad():
         ref = vggt_oracle.vggt_forward(cpu_sd, img, cfg.to_dict())
     assert _maxerr(torch.stack(out["pose_enc_list"]).cpu(), torch.stack(ref["pose_enc_list"])) < 1e-3
-    rel = (out["depth"].cpu() - ref["depth"]).abs() / (ref["depth"].abs() + 1.0)
+    key, ckey = ("depth", "depth_conf") if head == "depth" else ("world_points", "world_points_conf")
+    assert out[key].shape == ref[key].shape
+    rel = (out[key].cpu() - ref[key]).abs() / (ref[key].abs() + 1.0)
     assert rel.max().item() < 1e-3, rel.max().item()
-    relc = (out["depth_conf"].cpu() - ref["depth_conf"]).abs() / (ref["depth_conf"].abs() + 1.0)
+    relc = (out[ckey].cpu() - ref[ckey]).abs() / (ref[ckey].abs() + 1.0)
     assert relc.max().item() < 1e-3
