@@ -53,12 +53,20 @@ __device__ __forceinline__ void tile_coords256(const GemmArgs& p, int& tm, int& 
 // per-row `if (m < M)` turns into s_cbranch_execz + s_waitcnt vmcnt(0) per row, i.e. every store
 // waits for the previous one's round trip.  So the interior tiles (all but the last tile row /
 // column) take a branch-free straight-line path, and only edge tiles run the checked loop.
-template <int MT, int EPI>
+//
+// The residual epilogue (EPI 2) is a chain of global round trips per pass (residual load -> add ->
+// store, and loads wait behind older stores in vmcnt), so the residual rows of the next PF passes
+// are requested ahead: PF passes x 8 float4 = 32 PF registers.
+template <int MT, int EPI, int PF = 2>
 __device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT][2], char* smem, int wave, int lane,
                                             int wr, int wc, int m0, int n0) {
     const int l31 = lane & 31, lh = lane >> 5;
     float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
     const int n = n0 + wc * 64 + 4 * (lane & 15);
+    if (p.dbg & 8) {   // timing ablation: no epilogue (keeps the accumulators alive through one store)
+        if (acc[0][0][0] == 123.456f) ((float*)p.out)[0] = acc[MT - 1][1][15];
+        return;
+    }
     const bool interior = (m0 + 64 * MT <= p.M) && (n0 + 256 <= p.N) && !(p.dbg & 4);   // block-uniform
     float4 bs = make_float4(0, 0, 0, 0), gm = make_float4(1, 1, 1, 1);
     if (EPI != 0 && n < p.N) {
@@ -75,6 +83,39 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT]
         __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                    \
     } while (0)
 
+    if (EPI == 2 && interior) {
+        const int mrow0 = m0 + wr * (32 * MT) + (lane >> 4);
+        float4 r[PF][8];
+#pragma unroll
+        for (int i = 0; i < PF && i < MT; ++i)
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                r[i][it] = *reinterpret_cast<const float4*>((const float*)p.resid + (long)(mrow0 + i * 32 + it * 4) * p.ldr + n);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            SKIMI_ACC_TO_SLAB(i);
+            const int mrow = mrow0 + i * 32;
+            float4 v[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                v[it] = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + 4 * (lane & 15)]);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const float4 rr = r[i % PF][it];
+                f32x4 ov = {rr.x + gm.x * (v[it].x + bs.x), rr.y + gm.y * (v[it].y + bs.y),
+                            rr.z + gm.z * (v[it].z + bs.z), rr.w + gm.w * (v[it].w + bs.w)};
+                *reinterpret_cast<f32x4*>((float*)p.out + (long)(mrow + it * 4) * p.ldo + n) = ov;
+            }
+            if (i + PF < MT) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    r[i % PF][it] =
+                        *reinterpret_cast<const float4*>((const float*)p.resid + (long)(mrow + PF * 32 + it * 4) * p.ldr + n);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // slab reads retired before the next pass overwrites it
+        }
+        return;
+    }
     if (EPI != 0 && interior) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -84,26 +125,16 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT]
 #pragma unroll
             for (int it = 0; it < 8; ++it)
                 v[it] = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + 4 * (lane & 15)]);
-            if (EPI == 2) {
-                float4 r[8];
 #pragma unroll
-                for (int it = 0; it < 8; ++it)
-                    r[it] = *reinterpret_cast<const float4*>((const float*)p.resid + (long)(mrow + it * 4) * p.ldr + n);
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    f32x4 ov = {r[it].x + gm.x * (v[it].x + bs.x), r[it].y + gm.y * (v[it].y + bs.y),
-                                r[it].z + gm.z * (v[it].z + bs.z), r[it].w + gm.w * (v[it].w + bs.w)};
-                    *reinterpret_cast<f32x4*>((float*)p.out + (long)(mrow + it * 4) * p.ldo + n) = ov;
+            for (int it = 0; it < 8; ++it) {
+                float y0 = v[it].x + bs.x, y1 = v[it].y + bs.y, y2 = v[it].z + bs.z, y3 = v[it].w + bs.w;
+                if (EPI == 3) {
+                    const f32x2_t g0 = gelu_erf2(f32x2_t{y0, y1}), g1 = gelu_erf2(f32x2_t{y2, y3});
+                    y0 = g0.x; y1 = g0.y; y2 = g1.x; y3 = g1.y;
                 }
-            } else {
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    float y0 = v[it].x + bs.x, y1 = v[it].y + bs.y, y2 = v[it].z + bs.z, y3 = v[it].w + bs.w;
-                    if (EPI == 3) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
-                    bf16x4 hb;
-                    hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
-                    *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)(mrow + it * 4) * p.ldo + n) = hb;
-                }
+                bf16x4 hb;
+                hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
+                *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)(mrow + it * 4) * p.ldo + n) = hb;
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);   // slab reads retired before the next pass overwrites it
         }
@@ -287,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at their maxima)
 #define SKIMI_VMCNT(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
 
-template <int EPI>
+template <int EPI, int DEEP>
 __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GemmArgs p) {
     constexpr int MT = 4, BM = 256, BN = 256, BK = 64;
     constexpr int RB = 128;
@@ -354,8 +385,10 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GemmArgs p) {
     // prologue: all of K-tile 0, then the two quarters of K-tile 1 that the loop does not issue
     issue_a(0, 0); issue_w(0, 0); issue_w(1, 0); issue_a(1, 0);
     if (nkt > 1) {
-        issue_a(0, 1); issue_w(1, 1);
-        SKIMI_VMCNT(4);
+        issue_a(0, 1);
+        if (DEEP) issue_w(0, 1);
+        issue_w(1, 1);
+        if (DEEP) SKIMI_VMCNT(6); else SKIMI_VMCNT(4);
     } else {
         SKIMI_VMCNT(0);
     }
@@ -410,16 +443,19 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GemmArgs p) {
         SKIMI_QUADRANT(0, 0);
         // P2
         read_w(1);
-        if (kt + 1 < nkt) issue_w(0, kt + 1);
+        if (!DEEP && kt + 1 < nkt) issue_w(0, kt + 1);
         SKIMI_QUADRANT(0, 1);
         // P3
         read_a(1);
-        if (kt + 2 < nkt) issue_a(0, kt + 2);
+        if (kt + 2 < nkt) {
+            issue_a(0, kt + 2);
+            if (DEEP) issue_w(0, kt + 2);
+        }
         SKIMI_QUADRANT(1, 1);
         // P4
         if (kt + 2 < nkt) {
             issue_w(1, kt + 2);
-            SKIMI_VMCNT(4);
+            if (DEEP) SKIMI_VMCNT(6); else SKIMI_VMCNT(4);
         } else {
             SKIMI_VMCNT(0);
         }
@@ -431,6 +467,196 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GemmArgs p) {
     epilogue256<MT, EPI>(p, acc, smem, wave, lane, wr, wc, m0, n0);
 }
 
+
+// Single-stream loop: 4 waves (one per SIMD), each a 128x128 quadrant = 4x4 MFMA tiles (256
+// accumulator registers; the kernel runs at one wave per SIMD, so 512 are there).  Every wave
+// software-pipelines its own stream — the 8 fragment reads of k-step s+1 and its share of the
+// LDS-DMA go out between the 16 MFMAs of k-step s — and there is ONE workgroup barrier per K-tile
+// instead of eight hand-offs between two wave rows.  Fragment reads drop to 128 KiB per K-tile
+// (8 per 16 MFMAs) from 192 KiB.
+//
+// LDS is a ring of ten 16-KiB slots (all 160 KiB); a K-tile is four pieces of 128 rows x 128 B:
+// q = 0,1 the A rows of wave row 0 / 1, q = 2,3 the W rows of wave column 0 / 1; piece q of
+// K-tile kt sits in slot (4 kt + q) mod 10.  The two spare slots let half of K-tile kt+2 go out a
+// whole K-tile early:
+//   k-step 1, 2 of kt : issue (kt+2; q = 0), (kt+2; q = 1)      -> the slots K-tile kt-1's W left
+//   k-step 3 of kt    : lgkmcnt(0), vmcnt(8) = all of kt+1 landed, barrier (= K-tile kt released),
+//                       read (kt+1, k-step 0), issue (kt+2; q = 2, 3) -> K-tile kt's A slots
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const GemmArgs p) {
+    constexpr int RB = 128, BK = 64, PIECE = 128 * RB, NSLOT = 10;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int tm, tn;
+    tile_coords256(p, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nkt = p.K / BK;
+    // experiment: stagger the first round of workgroups (dbg bits 8..15 = units of ~0.85 us per
+    // step; bits 16..17 = what to stagger by: 0 XCD, 1 CU group of 8 within the XCD, 2 both)
+    if ((p.dbg >> 8) && blockIdx.x < 256) {
+        const int unit = (p.dbg >> 8) & 255, mode = (p.dbg >> 16) & 3;
+        const int step = mode == 0 ? (blockIdx.x & 7) : mode == 1 ? ((blockIdx.x >> 3) & 3) * 2 : (blockIdx.x & 7) + ((blockIdx.x >> 3) & 3) * 8;
+        for (int i = 0; i < step * unit; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+
+    // DMA: a piece is 16 wave-instructions (8 rows x 128 B each); this wave issues 4*wave + j
+    const unsigned short* src[4][4];   // [q][j]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (4 * wave + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            src[q][j] = q < 2 ? (const unsigned short*)p.A + (long)min(m0 + 128 * q + row, p.M - 1) * p.lda + c * 8
+                              : (const unsigned short*)p.W + (long)min(n0 + 128 * (q - 2) + row, p.N - 1) * p.ldw + c * 8;
+        }
+    auto issue = [&](int q, int kt, int slot) {
+        char* base = smem + slot * PIECE + (4 * wave) * 8 * RB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src[q][j] + kt * BK), (lds_void*)(base + j * 8 * RB), 16, 0, 0);
+    };
+
+    // fragment reads: row block i of this wave's A piece / W piece, k-step s
+    const int t = lh ^ ((l31 >> 1) & 7);
+    const int lane_off = l31 * RB;
+    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+    auto read = [&](int sb, int s, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
+        int sa = sb + wr, sw = sb + 2 + wc;
+        sa = sa >= NSLOT ? sa - NSLOT : sa;
+        sw = sw >= NSLOT ? sw - NSLOT : sw;
+        const char* pa = smem + sa * PIECE + lane_off + (((2 * s) ^ t) << 4);
+        const char* pw = smem + sw * PIECE + lane_off + (((2 * s) ^ t) << 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(pa + i * 32 * RB);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const bf16x8*>(pw + i * 32 * RB);
+    };
+
+    f32x16 acc[2][4][2];   // [column half h][row block i][column block j]: columns 64 h + 32 j
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+#define SKIMI_W4_MFMA(FA, FB)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 4; ++i)                 \
+        acc[j >> 1][i][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], FB[j], acc[j >> 1][i][j & 1], 0, 0, 0)
+
+    // prologue: K-tiles 0 and 1 whole
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue(q, 0, q);
+    if (nkt > 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue(q, 1, 4 + q);
+        SKIMI_VMCNT(16);
+    } else {
+        SKIMI_VMCNT(0);
+    }
+    SKIMI_BAR();
+    int sb = 0;   // slot of piece 0 of K-tile kt
+    read(sb, 0, fa0, fb0);
+    // One k-step: the fragments it multiplies were requested a whole k-step ago, so the lgkmcnt(0)
+    // in front is free; then the next k-step's 8 fragment reads and this k-step's DMA issues are
+    // dealt out between the first MFMAs (2 reads or 1 DMA per MFMA), the rest run back to back.
+#define SKIMI_W4_HEAD()                       \
+    do {                                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);   \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+#define SKIMI_W4_TAIL(NDMA)                                                        \
+    do {                                                                           \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                     \
+        }                                                                          \
+        _Pragma("unroll") for (int g = 0; g < NDMA; ++g) {                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                     \
+        }                                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 12 - NDMA, 0);                 \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    } while (0)
+    // one K-tile; N1 / N2: K-tiles kt+1 / kt+2 exist (literals: the main loop runs with both, the
+    // last two K-tiles are peeled so that the loop body is one straight-line scheduling region)
+#define SKIMI_W4_KTILE(N1, N2)                                                      \
+    do {                                                                            \
+        int s8 = sb + 8, s9 = sb + 9, s1 = sb + 1, nsb = sb + 4;                    \
+        s8 = s8 >= NSLOT ? s8 - NSLOT : s8;                                         \
+        s9 = s9 >= NSLOT ? s9 - NSLOT : s9;                                         \
+        s1 = s1 >= NSLOT ? s1 - NSLOT : s1;                                         \
+        nsb = nsb >= NSLOT ? nsb - NSLOT : nsb;                                     \
+        /* k-step 0 */                                                              \
+        SKIMI_W4_HEAD();                                                            \
+        read(sb, 1, fa1, fb1);                                                      \
+        SKIMI_W4_MFMA(fa0, fb0);                                                    \
+        SKIMI_W4_TAIL(0);                                                           \
+        /* k-step 1 */                                                              \
+        SKIMI_W4_HEAD();                                                            \
+        read(sb, 2, fa0, fb0);                                                      \
+        if (N2) issue(0, kt + 2, s8);                                               \
+        SKIMI_W4_MFMA(fa1, fb1);                                                    \
+        SKIMI_W4_TAIL((N2 ? 4 : 0));                                                \
+        /* k-step 2 */                                                              \
+        SKIMI_W4_HEAD();                                                            \
+        read(sb, 3, fa1, fb1);                                                      \
+        if (N2) issue(1, kt + 2, s9);                                               \
+        SKIMI_W4_MFMA(fa0, fb0);                                                    \
+        SKIMI_W4_TAIL((N2 ? 4 : 0));                                                \
+        /* k-step 3 */                                                              \
+        SKIMI_W4_HEAD();                                                            \
+        if (N1) {                                                                   \
+            if (N2) SKIMI_VMCNT(8); else SKIMI_VMCNT(0);                            \
+            SKIMI_BAR();                                                            \
+            read(nsb, 0, fa0, fb0);                                                 \
+            if (N2) {                                                               \
+                issue(2, kt + 2, sb);                                               \
+                issue(3, kt + 2, s1);                                               \
+            }                                                                       \
+        }                                                                           \
+        SKIMI_W4_MFMA(fa1, fb1);                                                    \
+        if (N1) SKIMI_W4_TAIL((N2 ? 8 : 0)); else __builtin_amdgcn_sched_barrier(0); \
+        sb = nsb;                                                                   \
+    } while (0)
+    int kt = 0;
+    for (; kt + 2 < nkt; ++kt) SKIMI_W4_KTILE(true, true);
+    if (kt + 1 < nkt) {
+        SKIMI_W4_KTILE(true, false);
+        ++kt;
+    }
+    SKIMI_W4_KTILE(false, false);
+#undef SKIMI_W4_KTILE
+#undef SKIMI_W4_HEAD
+#undef SKIMI_W4_TAIL
+#undef SKIMI_W4_MFMA
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    SKIMI_BAR();   // nobody reads operand pieces any more: the epilogue slabs alias slots 0 and 1
+
+    epilogue256<4, EPI, 4>(p, acc[0], smem, wave, lane, wr, 2 * wc, m0, n0);
+    epilogue256<4, EPI, 4>(p, acc[1], smem, wave, lane, wr, 2 * wc + 1, m0, n0);
+}
+
+
+// integer environment switch; read once, or on every call under SKIMI_ENV_DYNAMIC=1 (lets a timing
+// script alternate variants inside one process: boxes and thermal state differ by several percent)
+static int env_int(const char* name, int dflt, int& cache, bool& have) {
+    static const bool dynamic = getenv("SKIMI_ENV_DYNAMIC") && atoi(getenv("SKIMI_ENV_DYNAMIC"));
+    if (!have || dynamic) {
+        const char* v = getenv(name);
+        cache = v ? atoi(v) : dflt;
+        have = true;
+    }
+    return cache;
+}
+#define SKIMI_ENV_INT(NAME, DFLT) ([]() { static int c; static bool h = false; return env_int(NAME, DFLT, c, h); }())
 
 // which compile-time epilogue serves this launch (0 = generic)
 static int epi_kind(const GemmArgs& a) {
@@ -475,12 +701,12 @@ static int launch256(GemmArgs& a, hipStream_t st) {
     return SKIMI_OK;
 }
 
-template <int EPI>
-static int launch256pp(GemmArgs& a, hipStream_t st) {
+template <int EPI, int DEEP>
+static int launch256pp_(GemmArgs& a, hipStream_t st) {
     constexpr size_t lds = 2ull * (256 + 256) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_kernel<EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_kernel<EPI, DEEP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("hipFuncSetAttribute(gemm256pp) failed: %s", hipGetErrorString(e));
@@ -491,7 +717,34 @@ static int launch256pp(GemmArgs& a, hipStream_t st) {
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
     a.splitk = 1;
-    hipLaunchKernelGGL((gemm256pp_kernel<EPI>), dim3(a.ntm * a.ntn), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((gemm256pp_kernel<EPI, DEEP>), dim3(a.ntm * a.ntn), dim3(512), lds, st, a);
+    SKIMI_LAUNCH_CHECK();
+    return SKIMI_OK;
+}
+
+template <int EPI>
+static int launch256pp(GemmArgs& a, hipStream_t st) {
+    const int deep = SKIMI_ENV_INT("SKIMI_GEMM256_DEEP", 1);
+    return deep ? launch256pp_<EPI, 1>(a, st) : launch256pp_<EPI, 0>(a, st);
+}
+
+template <int EPI>
+static int launch256w4(GemmArgs& a, hipStream_t st) {
+    constexpr size_t lds = 10ull * 128 * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256w4_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(gemm256w4) failed: %s", hipGetErrorString(e));
+            return SKIMI_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    a.ntm = (int)cdiv(a.M, 256);
+    a.ntn = (int)cdiv(a.N, 256);
+    a.splitk = 1;
+    hipLaunchKernelGGL((gemm256w4_kernel<EPI>), dim3(a.ntm * a.ntn), dim3(256), lds, st, a);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }
@@ -499,21 +752,35 @@ static int launch256pp(GemmArgs& a, hipStream_t st) {
 // pick the tile height (192 or 256 rows) that wastes the fewest CU-rounds for this shape:
 // one workgroup per CU, so time ~ ceil(tiles / 256) * (rows per tile)
 int gemm256_launch(GemmArgs& a, hipStream_t st) {
-    static const int dbg = getenv("SKIMI_GEMM256_ABL") ? atoi(getenv("SKIMI_GEMM256_ABL")) : 0;
+    const int dbg = SKIMI_ENV_INT("SKIMI_GEMM256_ABL", 0);
     a.dbg = dbg;
     auto cost = [&](int bm) {
         const long tiles = cdiv(a.M, bm) * cdiv(a.N, 256);
         return (double)cdiv(tiles, 256) * bm;
     };
     const int epi = epi_kind(a);
-    // 192-row tiles (two-phase loop) when they waste fewer CU-rounds, else 256-row tiles on the
-    // ping-pong loop; SKIMI_GEMM256_PP=0 forces the two-phase loop (A/B timing)
-    static const int use_pp = getenv("SKIMI_GEMM256_PP") ? atoi(getenv("SKIMI_GEMM256_PP")) : 1;
-    if (cost(192) < cost(256)) {
+    // Which loop (measured on the aggregator shapes, M = 43968, interleaved A/B on one box):
+    //   * 192-row tiles on the two-phase loop only when they save a whole lot of CU-rounds: at equal
+    //     or slightly worse round counts the 256-row loops win (qkv: 301 us vs 267-281);
+    //   * single-stream loop (4 waves) where the main loop dominates (qkv, fc2: -2..-6 %); ping-pong
+    //     loop (8 waves) where the epilogue does (K <= 1024 with the residual epilogue, or GELU: its
+    //     chain of LDS / VALU / global round trips runs on twice the waves there).
+    // SKIMI_GEMM256_MT3 / _W4 / _PP = 0 / 1 force a choice (A/B timing).
+    const int use_pp = SKIMI_ENV_INT("SKIMI_GEMM256_PP", 1);
+    const int use_mt3 = SKIMI_ENV_INT("SKIMI_GEMM256_MT3", -1);
+    const int use_w4 = SKIMI_ENV_INT("SKIMI_GEMM256_W4", -1);
+    if (use_mt3 == 1 || (use_mt3 < 0 && cost(192) < 0.8 * cost(256))) {
         if (epi == 1) return launch256<3, 1>(a, st);
         if (epi == 2) return launch256<3, 2>(a, st);
         if (epi == 3) return launch256<3, 3>(a, st);
         return launch256<3, 0>(a, st);
+    }
+    const bool w4 = use_w4 >= 0 ? use_w4 != 0 : (epi == 1 || (epi == 2 && a.K > 1024));
+    if (w4) {
+        if (epi == 1) return launch256w4<1>(a, st);
+        if (epi == 2) return launch256w4<2>(a, st);
+        if (epi == 3) return launch256w4<3>(a, st);
+        return launch256w4<0>(a, st);
     }
     if (use_pp) {
         if (epi == 1) return launch256pp<1>(a, st);

@@ -6,6 +6,9 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+# kernel-variant switches of the library (SKIMI_GEMM256_*) are re-read on every launch, so that one
+# test process can walk through the variants (gemm256.hip: env_int)
+os.environ.setdefault("SKIMI_ENV_DYNAMIC", "1")
 GOLDEN = ROOT / "tests" / "golden"
 
 

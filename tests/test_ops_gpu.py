@@ -279,25 +279,57 @@ def test_attention_bf16_online_softmax_rescale():
     assert (out.float().cpu() - ref).abs().max().item() < 3e-2
 
 
+_GEMM256_VARIANTS = {  # SKIMI_GEMM256_* switches (gemm256_launch): "auto" is what the library picks
+    "auto": {},
+    "two_phase_192": {"SKIMI_GEMM256_MT3": "1"},
+    "ping_pong": {"SKIMI_GEMM256_MT3": "0", "SKIMI_GEMM256_W4": "0"},
+    "single_stream": {"SKIMI_GEMM256_MT3": "0", "SKIMI_GEMM256_W4": "1"},
+    "two_phase_256": {"SKIMI_GEMM256_MT3": "0", "SKIMI_GEMM256_W4": "0", "SKIMI_GEMM256_PP": "0"},
+}
+
+
+@pytest.mark.parametrize("variant", list(_GEMM256_VARIANTS))
 @pytest.mark.parametrize("M,N,K", [(2048, 512, 64), (4096, 1024, 128), (4300, 768, 192), (2100, 768, 1024),
                                    (10992, 1024, 4096),
-                                   # 256 tiles of 256 rows beat 192-row tiles -> ping-pong main loop
                                    (16384, 1024, 64), (16384, 1024, 128), (16300, 1000, 192), (16384, 1024, 1024)])
-def test_gemm256_lds_dma_path(M, N, K):
-    """bf16 x bf16 plain-row shapes with M >= 2048 take the 256x256 LDS-DMA kernels (two-phase
-    192-row tiles or the ping-pong 256-row loop, whichever wastes fewer CU rounds)."""
+def test_gemm256_lds_dma_path(M, N, K, variant, monkeypatch):
+    """bf16 x bf16 plain-row shapes with M >= 2048 take the 256x256 LDS-DMA kernels: the two-phase
+    loop (192- or 256-row tiles), the ping-pong loop or the single-stream 4-wave loop.  Every loop
+    is run on every shape (K of 1, 2, 3 and many K-tiles; ragged M and N)."""
+    for k, v in _GEMM256_VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
     a = (_rand(M, K, seed=70)).to(torch.bfloat16)
     w = (_rand(N, K, seed=71, scale=1 / math.sqrt(K))).to(torch.bfloat16)
     b, g, r = _rand(N, seed=72), _rand(N, seed=73), _rand(M, N, seed=74)
     ref = a.float() @ w.float().T
     out = ops.gemm(a, w, prec=PREC_BF16, bias=b, act=ACT_GELU, out_dtype=torch.bfloat16)
     assert _rel(out.float(), F.gelu(ref + b)) < 1e-2
+    out = ops.gemm(a, w, prec=PREC_BF16, bias=b, out_dtype=torch.bfloat16)
+    assert _rel(out.float(), ref + b) < 1e-2
     out = ops.gemm(a, w, prec=PREC_BF16, bias=b, gamma=g, resid=r)
     assert _rel(out, r + g * (ref + b)) < 1e-5 + 2e-3
     # exact integer data: any fragment / swizzle / row-map error shows as a wrong integer
     ai = ((torch.arange(M * K, device=DEV).reshape(M, K) * 7 + 3) % 9 - 4).to(torch.bfloat16)
     wi = ((torch.arange(N * K, device=DEV).reshape(N, K) * 5 + 1) % 7 - 3).to(torch.bfloat16)
     assert torch.equal(ops.gemm(ai, wi, prec=PREC_BF16), ai.float() @ wi.float().T)
+
+
+def test_gelu_epilogue_matches_erf_gelu():
+    """The packed two-value GELU of the bf16 epilogue (gemm_epilogue.h: gelu_erf2) against erf-GELU
+    over the whole input range, through an identity contraction: the output differs from the exact
+    value by bf16 rounding only."""
+    M, K = 4096, 64
+    x = torch.linspace(-9.0, 9.0, M * K, device=DEV).reshape(M, K)
+    # one-hot rows pick x[m, n % K] exactly (bf16 inputs: compare against the rounded input)
+    a = x.to(torch.bfloat16)
+    w = torch.zeros(512, K, device=DEV)
+    w[torch.arange(512), torch.arange(512) % K] = 1.0
+    out = ops.gemm(a, w.to(torch.bfloat16), prec=PREC_BF16, act=ACT_GELU, bias=torch.zeros(512, device=DEV),
+                   out_dtype=torch.bfloat16).float()
+    xin = a.float()[:, torch.arange(512, device=DEV) % K]
+    ref = F.gelu(xin.double()).float()
+    # bf16 rounding of the result: half an ulp = 2^-9 relative
+    assert ((out - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-6).all()
 
 
 def _x3(a, w, **kw):
