@@ -131,10 +131,11 @@ typedef struct skimi_gemm_desc {
     /* 1 = the caller guarantees the scratch is all zero on entry (every split-K launch leaves it
      * zeroed again), so no memset is issued; 0 = the launch zeroes what it needs first */
     int32_t splitk_scratch_zeroed;
-    /* optional fast path of SKIMI_PREC_BF16X3 for large shapes: W_split = the same weights as two
-     * bf16 planes [hi | lo], each [N, ldw] (skimi_split_planes), and x3_scratch = caller-owned
-     * scratch of >= 4 bytes per element of the A buffer the launch touches, where A is split once
-     * and from where the four planes stream through LDS-DMA.  Both NULL = generic kernel. */
+    /* optional fast path of SKIMI_PREC_BF16X3 for large shapes (M >= 4096, N > 128): W_split = the
+     * same weights as bf16 records [N][ceil(K/32)][hi 32 | lo 32] (skimi_split_records), and
+     * x3_scratch = caller-owned scratch of >= 4 bytes per element of the A buffer the launch touches
+     * (rows of ceil(C/32)*32 elements) + 256, where A is split once into the same records and from
+     * where both operands stream through LDS-DMA.  Both NULL, or a smaller scratch = generic kernel. */
     const void* W_split;
     void* x3_scratch;
     uint64_t x3_scratch_bytes;
@@ -143,6 +144,11 @@ typedef struct skimi_gemm_desc {
 /* fp32 [rows, C] (row stride ld elements) -> bf16 planes hi[rows, C], lo[rows, C]:
  * hi = bf16(x), lo = bf16(x - hi)  (operand form of SKIMI_PREC_BF16X3's fast path) */
 int skimi_split_planes(const float* x, int64_t ld, int64_t rows, int32_t C, void* hi, void* lo, void* stream);
+
+/* fp32 [rows, C] (row stride ld elements, C % 4 == 0) -> bf16 records [rows][ceil(C/32)][hi 32 | lo 32]
+ * (4 * rows * ceil(C/32) * 32 bytes; a ragged last slice is zero-filled): the hi and lo halves of
+ * a 32-element K-slice share one 128-byte line (operand form of skimi_gemm_desc.W_split) */
+int skimi_split_records(const float* x, int64_t ld, int64_t rows, int32_t C, void* records, void* stream);
 
 int skimi_gemm(const skimi_gemm_desc* d, void* stream);
 

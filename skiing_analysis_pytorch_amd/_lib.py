@@ -64,6 +64,7 @@ _SIGNATURES = {
                                     C.POINTER(C.c_double)]),
     "skimi_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "skimi_split_planes": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp]),
+    "skimi_split_records": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "skimi_resample_u8": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, C.c_int32, _vp]),
     "skimi_u8_hwc_to_f32_chw": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_float, _vp]),

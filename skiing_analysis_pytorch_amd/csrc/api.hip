@@ -126,6 +126,11 @@ int skimi_split_planes(const float* x, int64_t ld, int64_t rows, int32_t C, void
     return split_planes_launch(x, (long)ld, (long)rows, C, hi, lo, (hipStream_t)stream);
 }
 
+int skimi_split_records(const float* x, int64_t ld, int64_t rows, int32_t C, void* records, void* stream) {
+    SKIMI_CHECK_ARG(x && records && rows > 0 && C > 0, "skimi_split_records: bad arguments");
+    return split_records_launch(x, (long)ld, (long)rows, C, records, (hipStream_t)stream);
+}
+
 int skimi_layernorm(const float* x, const float* x2, int64_t ldx, int64_t rows, int32_t C,
                     const float* gamma, const float* beta, float eps, void* out, int32_t out_dtype,
                     int64_t ldo, void* stream) {

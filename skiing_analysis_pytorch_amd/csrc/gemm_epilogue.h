@@ -228,6 +228,8 @@ bool gemm_x3dma_eligible(const skimi_gemm_desc* d);
 int gemm_x3dma_launch(GemmArgs& a, const skimi_gemm_desc* d, hipStream_t st);
 size_t gemm_x3dma_scratch_bytes(const skimi_gemm_desc* d);
 int split_planes_launch(const float* x, long ld, long rows, int C, void* hi, void* lo, hipStream_t st);
+// fp32 [rows, C] -> records [rows][ceil(C/32)][hi 32 | lo 32] bf16 (operand form of the LDS-DMA bf16x3 kernel)
+int split_records_launch(const float* x, long ld, long rows, int C, void* rec, hipStream_t st, void* zpage = nullptr);
 int gemm256_launch(GemmArgs& a, hipStream_t st);
 
 }  // namespace skimi

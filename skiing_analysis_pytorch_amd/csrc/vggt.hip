@@ -37,7 +37,7 @@ struct Lin {              // out = A . W^T (+ b)
     float* b = nullptr;
     int N = 0, K = 0;     // K as seen by the GEMM (padded)
     int prec = SKIMI_PREC_BF16X3;
-    void* w_split = nullptr;   // BF16X3 only: bf16 [hi | lo] planes for the LDS-DMA kernel (wide 3x3 convs)
+    void* w_split = nullptr;   // BF16X3 only: bf16 [hi 32 | lo 32] records for the LDS-DMA kernel (wide 3x3 convs)
 };
 struct LNw { float* g = nullptr; float* b = nullptr; };
 struct BlockW {
@@ -221,15 +221,13 @@ struct Packer {
             perm = tmp;
         }
         c.lin = pack_matrix(perm, Co, Ci * k * k, prec);
-        // wide fp32-accurate 3x3 convs also get bf16 hi|lo planes: the LDS-DMA bf16x3 kernel
+        // wide fp32-accurate 3x3 convs also get bf16 hi|lo records: the LDS-DMA bf16x3 kernel
         // (gemm_x3dma.hip) beats the generic one there (measured: +28 % at 256 -> 256 channels;
         // no gain at N = 128 or for 1x1, which keep the generic kernel)
         if (!rc && prec == SKIMI_PREC_BF16X3 && k == 3 && Co >= 256 && Ci % 32 == 0) {
-            const size_t n = (size_t)Co * c.lin.K;
+            const size_t n = (size_t)Co * ((c.lin.K + 31) / 32 * 32);
             c.lin.w_split = dmalloc(n * 4);
-            if (c.lin.w_split)
-                rc = split_planes_launch((const float*)c.lin.w, c.lin.K, Co, c.lin.K, c.lin.w_split,
-                                         (unsigned short*)c.lin.w_split + n, st);
+            if (c.lin.w_split) rc = split_records_launch((const float*)c.lin.w, c.lin.K, Co, c.lin.K, c.lin.w_split, st);
         }
         if (tmp) { (void)hipStreamSynchronize(st); (void)hipFree(tmp); }
         if (bias) c.lin.b = keep(p + ".bias", Co);

@@ -126,6 +126,21 @@ def conv3x3_n32(x, w, bias=None, relu=False):
     return out
 
 
+def split_records(x):
+    """fp32 [rows, C] -> bf16 [rows, ceil(C/32), 2, 32]: (hi, lo) halves of every 32-element slice in
+    one 128-byte record (the `w_split` operand of `gemm`; a ragged last slice is zero-filled)."""
+    _require_cuda(x)
+    rows, Cc = x.shape
+    out = torch.empty((rows, (Cc + 31) // 32, 2, 32), dtype=torch.bfloat16, device=x.device)
+    check(lib().skimi_split_records(ptr(x), x.stride(0), rows, Cc, ptr(out), _lib.current_stream()), "skimi_split_records")
+    return out
+
+
+def x3_scratch_numel(rows, Cc):
+    """fp32 elements of the `x3_scratch` that `gemm(..., w_split=...)` needs for an A buffer of [rows, Cc]."""
+    return rows * ((Cc + 31) // 32 * 32) + 64
+
+
 def split_planes(x):
     """fp32 [rows, C] -> bf16 [2, rows, C] (hi, lo) with hi + lo ~= x to ~2^-17 relative."""
     _require_cuda(x)

@@ -116,8 +116,8 @@ def test_gemm_conv_gather_slice_major_k(cfg):
     out = ops.gemm(x.reshape(-1, Cc), wp, prec=PREC_BF16X3, bias=b, conv=conv)
     assert _rel(out, ref_cl) < 2e-5
     if Co >= 256:
-        scratch = torch.empty(x.numel(), dtype=torch.float32, device=DEV)
-        out2 = ops.gemm(x.reshape(-1, Cc), wp, prec=PREC_BF16X3, bias=b, conv=conv, w_split=ops.split_planes(wp), x3_scratch=scratch)
+        scratch = torch.empty(ops.x3_scratch_numel(x.numel() // Cc, Cc), dtype=torch.float32, device=DEV)
+        out2 = ops.gemm(x.reshape(-1, Cc), wp, prec=PREC_BF16X3, bias=b, conv=conv, w_split=ops.split_records(wp), x3_scratch=scratch)
         assert _rel(out2, ref_cl) < 2e-5
     # plain bf16 tiles are 64 deep: slice-major weights are refused, not mis-read
     with pytest.raises(Exception):
@@ -333,10 +333,22 @@ def test_gelu_epilogue_matches_erf_gelu():
 
 
 def _x3(a, w, **kw):
-    """bf16x3 fast path: weights also as pre-split planes + scratch for the activation planes."""
-    rows = a.shape[0]
-    scratch = torch.empty(rows * a.shape[1], dtype=torch.float32, device=DEV)
-    return ops.gemm(a, w, prec=PREC_BF16X3, w_split=ops.split_planes(w), x3_scratch=scratch, **kw)
+    """bf16x3 fast path: weights also as pre-split records + scratch for the activation records."""
+    conv = kw.get("conv")
+    rows, cc = (conv["N"] * conv["H"] * conv["W"], conv["C"]) if conv else a.shape
+    scratch = torch.empty(ops.x3_scratch_numel(rows, cc), dtype=torch.float32, device=DEV)
+    return ops.gemm(a, w, prec=PREC_BF16X3, w_split=ops.split_records(w), x3_scratch=scratch, **kw)
+
+
+def test_split_records_reconstructs():
+    x = _rand(1000, 200, seed=79) * 7          # ragged last slice: 200 = 6 * 32 + 8
+    p = ops.split_records(x)                    # [rows, 7, 2, 32]
+    assert p.shape == (1000, 7, 2, 32)
+    hi = p[:, :, 0].reshape(1000, -1).float()
+    lo = p[:, :, 1].reshape(1000, -1).float()
+    assert torch.equal(hi[:, :200], x.to(torch.bfloat16).float())
+    assert (((hi + lo)[:, :200] - x).abs() / x.abs().clamp_min(1e-20)).max().item() < 2 ** -15
+    assert (hi[:, 200:] == 0).all() and (lo[:, 200:] == 0).all()
 
 
 def test_split_planes_reconstructs():

@@ -67,6 +67,72 @@ __global__ __launch_bounds__(64 * NW) void k(const unsigned short* A, const unsi
     if (sink && tid == 0) sink[blockIdx.x] = *reinterpret_cast<int*>(smem + 64);
 }
 
+// the bf16x3 kernels' staging shape: BK = 32 -> 64-B rows, a wave-instruction covers 16 rows x 64 B;
+// a 16-KiB piece = one plane of 256 rows; pieces cycle A_hi, A_lo (two buffers), W_hi, W_lo
+template <int DEPTH>
+__global__ __launch_bounds__(256) void k64(const unsigned short* A, const unsigned short* A2, const unsigned short* W,
+                                           const unsigned short* W2, int K, int ntm, int ntn, int* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = 10;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    tile_coords(ntm, ntn, tm, tn);
+    const unsigned short* src[4][4];
+    int row0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        row0[j] = (4 * wave + j) * 16;
+        const int row = row0[j] + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        src[0][j] = A + (long)(tm * 256 + row) * K + c * 8;
+        src[1][j] = A2 + (long)(tm * 256 + row) * K + c * 8;
+        src[2][j] = W + (long)(tn * 256 + row) * K + c * 8;
+        src[3][j] = W2 + (long)(tn * 256 + row) * K + c * 8;
+    }
+    const int nkt = K / 32;
+    int slot = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(src[q][j] + kt * 32),
+                                                 (lds_void*)(smem + slot * 16384 + row0[j] * 64), 16, 0, 0);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            VMCNT(4 * (DEPTH - 1));
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    VMCNT(0);
+    __syncthreads();
+    if (sink && tid == 0) sink[blockIdx.x] = *reinterpret_cast<int*>(smem + 64);
+}
+
+template <int DEPTH>
+void run64(const unsigned short* A, const unsigned short* W, int M, int N, int K, int* sink) {
+    const int ntm = M / 256, ntn = N / 256;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k64<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const unsigned short* A2 = A + (size_t)M * K;
+    const unsigned short* W2 = W + (size_t)N * K;
+    for (int i = 0; i < 2; ++i) k64<DEPTH><<<ntm * ntn, 256, 163840>>>(A, A2, W, W2, K, ntm, ntn, sink);
+    hipEventRecord(e0);
+    const int R = 10;
+    for (int i = 0; i < R; ++i) k64<DEPTH><<<ntm * ntn, 256, 163840>>>(A, A2, W, W2, K, ntm, ntn, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / R;
+    const double bytes = (double)ntm * ntn * (K / 32) * 65536.0;
+    const double rounds = (ntm * ntn + 255) / 256;
+    printf("64-B rows: M %5d N %5d K %5d depth %d: %8.1f us  %6.1f GB/s per CU  %5.2f TB/s  %.2f us per 64 KiB K-tile\n", M, N, K, DEPTH,
+           us, bytes / 256 / us * 1e-3, bytes / us * 1e-6, us / rounds / (K / 32));
+    fflush(stdout);
+}
+
 template <int DEPTH, int BAR, int NW>
 void run(const unsigned short* A, const unsigned short* W, int M, int N, int K, int* sink) {
     const int ntm = M / 256, ntn = N / 256;
@@ -101,6 +167,11 @@ int main() {
     hipMalloc(&sink, 1 << 20);
     hipMemset(A, 0, (size_t)43968 * 4096 * 2);
     hipMemset(W, 0, (size_t)N * K * 2);
+    run64<2>(A, W, 8192, 2048, 2304, sink);
+    run64<4>(A, W, 8192, 2048, 2304, sink);
+    run64<6>(A, W, 8192, 2048, 2304, sink);
+    run64<4>(A, W, 65536, 256, 2304, sink);
+    run64<6>(A, W, 65536, 256, 2304, sink);
     run<1, 1, 8>(A, W, M, N, K, sink);
     run<2, 1, 8>(A, W, M, N, K, sink);
     run<3, 1, 8>(A, W, M, N, K, sink);
