@@ -41,6 +41,7 @@ extern "C" {
 /* element types of buffers that cross the ABI */
 #define SKIMI_F32 0
 #define SKIMI_BF16 1
+#define SKIMI_BF16X3_REC 2 /* skimi_gemm_desc.a_dtype only: A already split into [hi 32 | lo 32] records */
 
 /* arithmetic mode of the MFMA contractions
  *   SKIMI_PREC_BF16   : operands rounded to bf16, one v_mfma_f32_32x32x16_bf16 per
@@ -83,7 +84,7 @@ typedef struct skimi_gemm_desc {
     int32_t M, N, K;          /* out rows, out cols, contraction length (K % 8 == 0) */
     const void* A;            /* dev; [rows, lda] f32 or bf16, channels-last */
     const void* W;            /* dev; [N, ldw] f32 (BF16X3) or bf16 (BF16): nn.Linear layout */
-    int32_t a_dtype, w_dtype; /* SKIMI_F32 / SKIMI_BF16 */
+    int32_t a_dtype, w_dtype; /* SKIMI_F32 / SKIMI_BF16; a_dtype SKIMI_BF16X3_REC: see W_split */
     int64_t lda, ldw;         /* in elements */
     int32_t prec;             /* SKIMI_PREC_* */
     /* A gather: a_mode 0 = plain rows; 1 = implicit im2col of a channels-last image
@@ -131,11 +132,16 @@ typedef struct skimi_gemm_desc {
     /* 1 = the caller guarantees the scratch is all zero on entry (every split-K launch leaves it
      * zeroed again), so no memset is issued; 0 = the launch zeroes what it needs first */
     int32_t splitk_scratch_zeroed;
-    /* optional fast path of SKIMI_PREC_BF16X3 for large shapes (M >= 4096, N > 128): W_split = the
-     * same weights as bf16 records [N][ceil(K/32)][hi 32 | lo 32] (skimi_split_records), and
-     * x3_scratch = caller-owned scratch of >= 4 bytes per element of the A buffer the launch touches
-     * (rows of ceil(C/32)*32 elements) + 256, where A is split once into the same records and from
-     * where both operands stream through LDS-DMA.  Both NULL, or a smaller scratch = generic kernel. */
+    /* optional fast path of SKIMI_PREC_BF16X3 for large shapes (M >= 4096, N >= 96, enough 256-row
+     * tiles to fill the chip): W_split = the same weights as bf16 records [N][ceil(K/32)][hi 32 | lo 32]
+     * (skimi_split_records), and x3_scratch = caller-owned scratch of >= 4 bytes per element of the A
+     * buffer the launch touches (rows of ceil(C/32)*32 elements) + 256, where A is split once into
+     * the same records and from where both operands stream through LDS-DMA.  Both NULL, or a smaller
+     * scratch = generic kernel.
+     * a_dtype SKIMI_BF16X3_REC: A already IS those records (of the [rows, C] buffer the launch
+     * touches; lda ignored) and x3_scratch points to >= 256 zero bytes that lie behind the records
+     * within 4 GiB of A (padding taps read them); such a launch must qualify for the fast path
+     * (skimi_gemm returns SKIMI_ERR_ARG otherwise). */
     const void* W_split;
     void* x3_scratch;
     uint64_t x3_scratch_bytes;

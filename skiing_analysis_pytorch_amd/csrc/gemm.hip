@@ -447,12 +447,15 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
                  (!d->resid2 || ((((uintptr_t)d->resid2) & 7) == 0 && (d->resid_dtype != SKIMI_F32 || al16(d->resid2)) && d->ldr2 % 4 == 0)) && (d->store_mode == 0 || d->ps_C % 4 == 0);
     }
 
-    // fp32-accurate path with pre-split weight planes: LDS-DMA bf16x3 kernel (gemm_x3dma.hip)
+    // fp32-accurate path with pre-split weight records: LDS-DMA bf16x3 kernel (gemm_x3dma.hip)
     if (force_splitk <= 0 && gemm_x3dma_eligible(d)) {
         a.partial = nullptr;
         a.k_per_split = d->K;
         return gemm_x3dma_launch(a, d, st);
     }
+    SKIMI_CHECK_ARG(d->a_dtype != SKIMI_BF16X3_REC,
+                    "skimi_gemm: A given as bf16x3 records, but the launch does not qualify for the LDS-DMA kernel "
+                    "(M=%d N=%d: needs W_split, M >= 4096, N >= 96, >= 200 tiles of 256 rows, a zero page behind A)", d->M, d->N);
 
     // large bf16 x bf16 plain-row shapes: 256x256 tiles staged by LDS-DMA (gemm256.hip)
     if (force_splitk <= 0 && gemm256_eligible(d)) {

@@ -205,6 +205,13 @@ struct Packer {
         L.b = keep(bkey, N);
         return L;
     }
+    // bf16 [hi 32 | lo 32] records of a packed fp32 matrix, for the LDS-DMA bf16x3 kernel (which
+    // gemm_x3dma_eligible then picks for launches that fill the chip with 256-row tiles)
+    void add_records(Lin& L) {
+        const size_t n = (size_t)L.N * ((L.K + 31) / 32 * 32);
+        L.w_split = dmalloc(n * 4);
+        if (L.w_split) rc = split_records_launch((const float*)L.w, L.K, L.N, L.K, L.w_split, st);
+    }
     ConvW conv(const std::string& p, int Co, int Ci, int k, int stride, int pad, int prec, bool bias) {
         ConvW c;
         c.k = k; c.stride = stride; c.pad = pad; c.cin = Ci;
@@ -221,14 +228,11 @@ struct Packer {
             perm = tmp;
         }
         c.lin = pack_matrix(perm, Co, Ci * k * k, prec);
-        // wide fp32-accurate 3x3 convs also get bf16 hi|lo records: the LDS-DMA bf16x3 kernel
-        // (gemm_x3dma.hip) beats the generic one there (measured: +28 % at 256 -> 256 channels;
-        // no gain at N = 128 or for 1x1, which keep the generic kernel)
-        if (!rc && prec == SKIMI_PREC_BF16X3 && k == 3 && Co >= 256 && Ci % 32 == 0) {
-            const size_t n = (size_t)Co * ((c.lin.K + 31) / 32 * 32);
-            c.lin.w_split = dmalloc(n * 4);
-            if (c.lin.w_split) rc = split_records_launch((const float*)c.lin.w, c.lin.K, Co, c.lin.K, c.lin.w_split, st);
-        }
+        // fp32-accurate 3x3 convs, wide 1x1 projections and the ConvTranspose matrices also get bf16
+        // hi|lo records: the LDS-DMA bf16x3 kernel (gemm_x3dma.hip) beats the generic one wherever
+        // 256-row tiles fill the chip
+        if (!rc && prec == SKIMI_PREC_BF16X3 && Ci % 32 == 0 && ((k == 3 && Co >= 96) || (k == 1 && Co >= 512)))
+            add_records(c.lin);
         if (tmp) { (void)hipStreamSynchronize(st); (void)hipFree(tmp); }
         if (bias) c.lin.b = keep(p + ".bias", Co);
         return c;
@@ -243,6 +247,7 @@ struct Packer {
         if (hipMalloc((void**)&tmp, (size_t)C * C * s * s * 4) != hipSuccess) { rc = SKIMI_ERR_HIP; return L; }
         if ((rc = permute_convT_launch(src, tmp, C, C, s, st))) return L;
         L = pack_matrix(tmp, s * s * C, C, prec);
+        if (!rc && prec == SKIMI_PREC_BF16X3 && C % 32 == 0) add_records(L);
         (void)hipStreamSynchronize(st);
         (void)hipFree(tmp);
         L.b = (float*)dmalloc((size_t)s * s * C * 4);
@@ -475,6 +480,7 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
     }
     // RefineNet fusion 4 -> 1 (dpt_head.py:261-291, 427-456)
     void* prev = nullptr;   // previous refinenet output at this level's resolution
+    char* prev_rec = nullptr;   // ... or, after the last level, the same map as bf16x3 operand records
     for (int r = 3; r >= 0; --r) {
         const FusionW& f = w.ref[r];
         const int h0 = hh[r], w0 = ww[r];
@@ -521,6 +527,29 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
             auto d = c.desc(f.out_conv, u, adt, feat, M, olow, adt, feat);
             c.gemm(d);
         }
+        // The last level's upsampled map is read by output_conv1 only: when that conv runs on the
+        // LDS-DMA bf16x3 kernel the upsample writes its operand records ([C/32][hi 32 | lo 32] per
+        // pixel + the zero page) instead of fp32 (no fp32 round trip, no split pass).
+        if (r == 0 && adt == SKIMI_F32 && w.oc1.lin.w_split != nullptr && feat % 32 == 0) {
+            const size_t rec_bytes = (size_t)F * h1 * w1 * feat * 4;
+            const size_t mk_rec = c.ar.mark();
+            char* rec = (char*)c.ar.alloc(rec_bytes + 256);
+            auto d = c.desc(w.oc1.lin, rec, SKIMI_BF16X3_REC, feat, F * h1 * w1, nullptr, adt, w.feature_only ? feat : feat / 2);
+            c.conv_geom(d, w.oc1, F, h1, w1, h1, w1);
+            d.x3_scratch = rec + rec_bytes;
+            d.x3_scratch_bytes = 256;
+            d.out = rec;   // placeholder for the eligibility query only
+            if (gemm_x3dma_eligible(&d)) {   // pointer-independent up to alignment: the sizing pass agrees
+                prev_rec = rec;
+                if (!c.rc && !c.dry())
+                    c.rc = bilinear_ac_planes_launch((const float*)olow, (unsigned short*)rec, F, h0, w0, h1, w1, feat, c.st,
+                                                     nullptr, nullptr, 1, rec + rec_bytes);
+                prev = nullptr;
+                hh[r] = h1; ww[r] = w1;
+                continue;
+            }
+            c.ar.release(mk_rec);
+        }
         void* o = c.ar.alloc((size_t)F * h1 * w1 * feat * es);
         if (!c.rc && !c.dry()) c.rc = bilinear_ac_launch(olow, o, adt, F, h0, w0, h1, w1, feat, c.st);
         prev = o;
@@ -529,7 +558,13 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
     const int h1 = hh[0], w1 = ww[0];
     const int f2 = w.feature_only ? feat : feat / 2;
     void* c1 = c.ar.alloc((size_t)F * h1 * w1 * f2 * es);
-    {
+    if (prev_rec != nullptr) {
+        auto d = c.desc(w.oc1.lin, prev_rec, SKIMI_BF16X3_REC, feat, F * h1 * w1, c1, adt, f2);
+        c.conv_geom(d, w.oc1, F, h1, w1, h1, w1);
+        d.x3_scratch = prev_rec + (size_t)F * h1 * w1 * feat * 4;
+        d.x3_scratch_bytes = 256;
+        if (!c.rc && !c.dry()) c.rc = gemm_dispatch(&d, c.st, c.slab, c.slab_bytes, 0);
+    } else {
         auto d = c.desc(w.oc1.lin, prev, adt, feat, F * h1 * w1, c1, adt, f2);
         c.conv_geom(d, w.oc1, F, h1, w1, h1, w1);
         c.gemm(d);

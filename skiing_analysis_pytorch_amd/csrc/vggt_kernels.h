@@ -8,7 +8,8 @@ int patch_gather_launch(const float* img, void* out, int out_dtype, int F, int H
                         hipStream_t st);
 int special_tokens_launch(float* x, const float* table, int F, int S, int P, int n, int C, hipStream_t st);
 int bilinear_ac_planes_launch(const float* in, unsigned short* out, int N, int h, int w, int H, int W, int C, hipStream_t st,
-                              const float* tabx = nullptr, const float* taby = nullptr);   // out: [N, H, W, hi C | lo C] bf16
+                              const float* tabx = nullptr, const float* taby = nullptr,
+                              int slice_records = 0, void* zpage = nullptr);   // out: [N, H, W, hi C | lo C] bf16
 int bilinear_ac_launch(const void* in, void* out, int dtype, int N, int h, int w, int H, int W, int C,
                        hipStream_t st, const float* tabx = nullptr, const float* taby = nullptr);
 int add_uv_pos_launch(void* x, int dtype, const float* tabx, const float* taby, int N, int H, int W, int C,

@@ -151,7 +151,11 @@ __global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ 
 __global__ __launch_bounds__(256) void bilinear_ac_planes_kernel(const float* __restrict__ in,
                                                                  unsigned short* __restrict__ out, int N, int h, int w,
                                                                  int H, int W, int C, const float* __restrict__ tabx,
-                                                                 const float* __restrict__ taby) {
+                                                                 const float* __restrict__ taby, int slice_records,
+                                                                 uint4* __restrict__ zpage) {
+    // slice_records: pixel = [C/32][hi 32 | lo 32] (operand records of the LDS-DMA bf16x3 GEMM) instead of
+    // [hi C | lo C]; zpage: 256 bytes to clear (that kernel's zero page, behind the records)
+    if (zpage != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) zpage[threadIdx.x] = uint4{0, 0, 0, 0};
     // 8 channels per thread: 16-B stores into each plane
     // one output row (n, Y) per blockIdx.y; threads run over X * C/8: only 32-bit index math
     const int C8 = C / 8;
@@ -196,20 +200,29 @@ __global__ __launch_bounds__(256) void bilinear_ac_planes_kernel(const float* __
             hi[k] = (short)hb;
             lo[k] = (short)f2bf(r[k] - bf2f(hb));
         }
-        const long o = ((n * H + Y) * (long)W + X) * 2 * C + c8 * 8;
-        *reinterpret_cast<bf16x8*>(out + o) = hi;
-        *reinterpret_cast<bf16x8*>(out + o + C) = lo;
+        const long pix = ((n * H + Y) * (long)W + X) * 2 * C;
+        if (slice_records) {
+            const int c = c8 * 8;
+            const long o = pix + (c >> 5) * 64 + (c & 31);
+            *reinterpret_cast<bf16x8*>(out + o) = hi;
+            *reinterpret_cast<bf16x8*>(out + o + 32) = lo;
+        } else {
+            const long o = pix + c8 * 8;
+            *reinterpret_cast<bf16x8*>(out + o) = hi;
+            *reinterpret_cast<bf16x8*>(out + o + C) = lo;
+        }
     }
 }
 
 int bilinear_ac_planes_launch(const float* in, unsigned short* out, int N, int h, int w, int H, int W, int C, hipStream_t st,
-                              const float* tabx, const float* taby) {
+                              const float* tabx, const float* taby, int slice_records, void* zpage) {
     SKIMI_CHECK_ARG(C % 16 == 0, "bilinear resize into planes needs C %% 16 == 0");
+    SKIMI_CHECK_ARG(!slice_records || C % 32 == 0, "bilinear resize into records needs C %% 32 == 0");
     SKIMI_CHECK_ARG(tabx == nullptr || taby != nullptr, "fused uv pos embed needs both tables");
     SKIMI_CHECK_ARG((long)N * H < 65536, "bilinear resize into planes: N * H must be < 65536");
     const int rowlen = W * (C / 8);
     hipLaunchKernelGGL(bilinear_ac_planes_kernel, dim3((unsigned)cdiv(rowlen, 256), (unsigned)(N * H)), dim3(256), 0, st, in, out, N,
-                       h, w, H, W, C, tabx, taby);
+                       h, w, H, W, C, tabx, taby, slice_records, (uint4*)zpage);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }

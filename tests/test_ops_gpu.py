@@ -98,10 +98,12 @@ def test_gemm_conv_gather(cfg, prec):
 
 
 @pytest.mark.parametrize("cfg", [dict(H=37, W=37, C=64, Co=96, k=3, s=1, p=1), dict(H=19, W=23, C=128, Co=32, k=3, s=2, p=1),
-                                 dict(H=30, W=30, C=256, Co=256, k=3, s=1, p=1)])
-def test_gemm_conv_gather_slice_major_k(cfg):
-    """a_mode 2: the same 3x3 gather with K ordered [Cin/32][ky][kx][32] (weights packed to match); the last
-    shape (Cout 256, pre-split planes) takes the LDS-DMA bf16x3 kernel."""
+                                 dict(H=30, W=30, C=256, Co=256, k=3, s=1, p=1), dict(H=50, W=47, C=256, Co=256, k=3, s=1, p=1),
+                                 dict(H=61, W=40, C=96, Co=128, k=3, s=1, p=1), dict(H=121, W=117, C=64, Co=256, k=3, s=2, p=1)])
+def test_gemm_conv_gather_slice_major_k(cfg, x3_small_shapes):
+    """a_mode 2: the same 3x3 gather with K ordered [Cin/32][ky][kx][32] (weights packed to match); the
+    shapes with >= 4096 output pixels and Cout >= 96 also go through the LDS-DMA bf16x3 kernels (256- and
+    128-column tiles, ragged last tile rows, stride 2)."""
     H, W_, Cc, Co, k, s, p = (cfg[x] for x in ("H", "W", "C", "Co", "k", "s", "p"))
     n = 2
     x = _rand(n, H, W_, Cc, seed=20)
@@ -115,7 +117,7 @@ def test_gemm_conv_gather_slice_major_k(cfg):
     ref_cl = ref.permute(0, 2, 3, 1).reshape(-1, Co)
     out = ops.gemm(x.reshape(-1, Cc), wp, prec=PREC_BF16X3, bias=b, conv=conv)
     assert _rel(out, ref_cl) < 2e-5
-    if Co >= 256:
+    if Co >= 96:
         scratch = torch.empty(ops.x3_scratch_numel(x.numel() // Cc, Cc), dtype=torch.float32, device=DEV)
         out2 = ops.gemm(x.reshape(-1, Cc), wp, prec=PREC_BF16X3, bias=b, conv=conv, w_split=ops.split_records(wp), x3_scratch=scratch)
         assert _rel(out2, ref_cl) < 2e-5
@@ -332,6 +334,12 @@ def test_gelu_epilogue_matches_erf_gelu():
     assert ((out - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-6).all()
 
 
+@pytest.fixture
+def x3_small_shapes(monkeypatch):
+    """The LDS-DMA bf16x3 kernels are only picked for launches of >= 200 tiles; let test shapes through."""
+    monkeypatch.setenv("SKIMI_X3_MIN_TILES", "1")
+
+
 def _x3(a, w, **kw):
     """bf16x3 fast path: weights also as pre-split records + scratch for the activation records."""
     conv = kw.get("conv")
@@ -359,8 +367,9 @@ def test_split_planes_reconstructs():
     assert torch.equal(p[0], x.to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("M,N,K", [(4096, 256, 256), (5000, 128, 1024), (10952, 256, 2048), (4100, 512, 392)])
-def test_gemm_x3dma_plain(M, N, K):
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 256), (5000, 128, 1024), (10952, 256, 2048), (4100, 512, 392), (4200, 128, 32),
+                                   (4300, 96, 64), (4097, 128, 96), (4500, 1024, 128), (4096, 256, 32), (4096, 256, 64)])
+def test_gemm_x3dma_plain(M, N, K, x3_small_shapes):
     a, w, b, r = _rand(M, K, seed=81), _rand(N, K, seed=82, scale=1 / math.sqrt(K)), _rand(N, seed=83), _rand(M, N, seed=84)
     ref = a @ w.T + b
     assert _rel(_x3(a, w, bias=b), ref) < 2e-5
@@ -371,8 +380,9 @@ def test_gemm_x3dma_plain(M, N, K):
 
 
 @pytest.mark.parametrize("cfg", [dict(H=74, W=74, C=64, Co=256, k=3, s=1, p=1), dict(H=75, W=73, C=128, Co=128, k=3, s=2, p=1),
-                                 dict(H=70, W=70, C=32, Co=256, k=3, s=1, p=1)])
-def test_gemm_x3dma_conv(cfg):
+                                 dict(H=70, W=70, C=32, Co=256, k=3, s=1, p=1), dict(H=80, W=61, C=64, Co=128, k=3, s=1, p=1),
+                                 dict(H=66, W=70, C=32, Co=100, k=3, s=1, p=1)])
+def test_gemm_x3dma_conv(cfg, x3_small_shapes):
     H, W_, Cc, Co, k, s, p = (cfg[x] for x in ("H", "W", "C", "Co", "k", "s", "p"))
     n = 2
     x = _rand(n, H, W_, Cc, seed=85)
@@ -387,7 +397,7 @@ def test_gemm_x3dma_conv(cfg):
     assert _rel(out, ref.permute(0, 2, 3, 1).reshape(-1, Co)) < 2e-5
 
 
-def test_gemm_x3dma_pixel_shuffle():
+def test_gemm_x3dma_pixel_shuffle(x3_small_shapes):
     n, H, W_, Cc, Co, s = 3, 37, 37, 256, 256, 2
     x = _rand(n, H, W_, Cc, seed=88)
     w = _rand(Cc, Co, s, s, seed=89, scale=0.1)
