@@ -63,6 +63,8 @@ extern "C" {
 
 const char* skimi_last_error(void);
 int skimi_version(void);
+/* sizeof(skimi_gemm_desc) as this library was built: a binding checks its own struct against it */
+int skimi_sizeof_gemm_desc(void);
 /* number of HIP devices visible; does not initialise a context on any */
 int skimi_device_count(void);
 
@@ -145,6 +147,11 @@ typedef struct skimi_gemm_desc {
     const void* W_split;
     void* x3_scratch;
     uint64_t x3_scratch_bytes;
+    /* dev or NULL: the result also (or, with out == NULL, only) as bf16x3 records
+     * [M][ceil(N/32)][hi 32 | lo 32] followed by 256 zero bytes (4 * M * ceil(N/32) * 32 + 256 bytes,
+     * 128-byte aligned; N % 32 == 0, plain output rows): the a_dtype SKIMI_BF16X3_REC operand of a
+     * following contraction, written by this launch's epilogue instead of a separate split pass */
+    void* out_records;
 } skimi_gemm_desc;
 
 /* fp32 [rows, C] (row stride ld elements) -> bf16 planes hi[rows, C], lo[rows, C]:

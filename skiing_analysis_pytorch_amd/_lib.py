@@ -12,6 +12,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libskimi.so"
 
 F32, BF16 = 0, 1
+BF16X3_REC = 2   # skimi_gemm_desc.a_dtype: A already split into bf16x3 records
 PREC_BF16, PREC_BF16X3 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
 
@@ -50,6 +51,7 @@ class GemmDesc(C.Structure):
         ("splitk_scratch_bytes", C.c_uint64),
         ("force_splitk", C.c_int32), ("splitk_scratch_zeroed", C.c_int32),
         ("W_split", C.c_void_p), ("x3_scratch", C.c_void_p), ("x3_scratch_bytes", C.c_uint64),
+        ("out_records", C.c_void_p),
     ]
 
 
@@ -58,6 +60,7 @@ _vp = C.c_void_p
 _SIGNATURES = {
     "skimi_last_error": (C.c_char_p, []),
     "skimi_version": (C.c_int, []),
+    "skimi_sizeof_gemm_desc": (C.c_int, []),
     "skimi_device_count": (C.c_int, []),
     "skimi_profile_start": (C.c_int, [C.c_int32, C.c_int64]),
     "skimi_profile_stop": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -125,6 +128,9 @@ def lib() -> C.CDLL:
             raise SkimiError(f"libskimi.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    if handle.skimi_sizeof_gemm_desc() != C.sizeof(GemmDesc):
+        raise SkimiError(f"skimi_gemm_desc is {handle.skimi_sizeof_gemm_desc()} bytes in libskimi.so but "
+                         f"{C.sizeof(GemmDesc)} in _lib.py: rebuild the library (python -m skiing_analysis_pytorch_amd.build)")
     _lib = handle
     return _lib
 

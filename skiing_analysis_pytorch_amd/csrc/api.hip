@@ -56,6 +56,7 @@ extern "C" {
 const char* skimi_last_error(void) { return g_err; }
 
 int skimi_version(void) { return 100; }
+int skimi_sizeof_gemm_desc(void) { return (int)sizeof(skimi_gemm_desc); }
 
 int skimi_device_count(void) {
     int n = 0;

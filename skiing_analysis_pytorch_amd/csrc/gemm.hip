@@ -399,7 +399,19 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     SKIMI_CHECK_ARG(d != nullptr, "skimi_gemm: null descriptor");
     SKIMI_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "skimi_gemm: empty shape M=%d N=%d K=%d", d->M, d->N, d->K);
     SKIMI_CHECK_ARG(d->K % 8 == 0, "skimi_gemm: K=%d must be a multiple of 8", d->K);
-    SKIMI_CHECK_ARG(d->A && d->W && d->out, "skimi_gemm: null buffer");
+    SKIMI_CHECK_ARG(d->A && d->W && (d->out || d->out_records), "skimi_gemm: null buffer");
+    if (d->out_records) {
+        SKIMI_CHECK_ARG(d->N % 32 == 0 && d->store_mode == 0 && d->out_rows_per_batch == 0 && d->out_row_off == 0 &&
+                            d->out2 == nullptr && ((uintptr_t)d->out_records & 127) == 0,
+                        "skimi_gemm: out_records needs N %% 32 == 0, plain output rows, no out2, 128-byte alignment");
+        SKIMI_CHECK_ARG(d->out || d->out_dtype == SKIMI_F32, "skimi_gemm: records-only output is written from fp32 results");
+        SKIMI_CHECK_ARG(d->prec == SKIMI_PREC_BF16X3, "skimi_gemm: out_records is an output form of the fp32-accurate mode");
+        // the zero page behind the records (padding taps of the consumer's gather)
+        if (hipMemsetAsync((char*)d->out_records + (size_t)d->M * (d->N / 32) * 128, 0, 256, st) != hipSuccess) {
+            set_error("hipMemsetAsync(out_records zero page) failed");
+            return SKIMI_ERR_HIP;
+        }
+    }
     SKIMI_CHECK_ARG(d->lda % 4 == 0 && d->ldw % 8 == 0 && d->lda >= 0,
                     "skimi_gemm: lda/ldw must keep 16-B alignment (lda=%ld ldw=%ld)", (long)d->lda, (long)d->ldw);
     SKIMI_CHECK_ARG(!(d->a_dtype == SKIMI_BF16 && d->lda % 8 != 0), "skimi_gemm: bf16 lda must be a multiple of 8");
@@ -436,6 +448,8 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     a.act = d->act;
     a.out = d->out; a.out2 = d->out2; a.out_dtype = d->out_dtype; a.ldo = d->ldo; a.ldo2 = d->ldo2;
     a.store_mode = d->store_mode; a.ps_s = d->ps_s; a.ps_C = d->ps_C;
+    a.out_rec = (unsigned short*)d->out_records;
+    a.rec_row = (long)(d->N / 32) * 64;
     a.partial = nullptr;
     {
         auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };

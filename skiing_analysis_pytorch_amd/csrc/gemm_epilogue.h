@@ -39,7 +39,24 @@ struct GemmArgs {
     int ntm, ntn;
     int vec4;          // epilogue may use 16-B accesses (N, ld*, pointers all 4-element aligned)
     int dbg;           // diagnostics only (gemm256 ablation: bit0 skip staging, bit1 skip MFMA phase)
+    unsigned short* out_rec;   // or NULL: result rows also as bf16x3 records [M][N/32][hi 32 | lo 32]
+    long rec_row;              // elements per record row = N/32 * 64
 };
+
+// columns n..n+3 of row m into the records (8-byte stores; 8 lanes fill one 128-byte record)
+__device__ __forceinline__ void store_rec4(const GemmArgs& p, long m, int n, float v0, float v1, float v2, float v3) {
+    const float f[4] = {v0, v1, v2, v3};
+    bf16x4 h, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned short hb = f2bf(f[k]);
+        h[k] = (short)hb;
+        l[k] = (short)f2bf(f[k] - bf2f(hb));
+    }
+    unsigned short* q = p.out_rec + m * p.rec_row + (n >> 5) * 64 + (n & 31);
+    *reinterpret_cast<bf16x4*>(q) = h;
+    *reinterpret_cast<bf16x4*>(q + 32) = l;
+}
 
 // erf-GELU with erfc by Abramowitz & Stegun 7.1.26 (|err| <= 1.5e-7 absolute, i.e. fp32 rounding
 // level on O(1) activations): branch-free, ~16 VALU ops.  libm's erff/expf inline to ~1 KB of
@@ -106,10 +123,12 @@ struct RowMap {
     long out2_off;  // same for out2
     long res_off;
     long res2_off;
+    long row;       // m (index of the record row when the launch also writes records)
 };
 
 __device__ __forceinline__ RowMap row_map(const GemmArgs& p, int m) {
     RowMap r;
+    r.row = m;
     if (p.store_mode == 0) {
         long mo = m;
         if (p.out_rpb > 0) {
@@ -162,6 +181,13 @@ __device__ __forceinline__ void store_one(const GemmArgs& p, const RowMap& rm, i
         o = pix * p.ldo + co;
         o2 = pix * p.ldo2 + co;
     }
+    if (p.out_rec) {   // plain output rows only (checked at dispatch)
+        const unsigned short hb = f2bf(v);
+        unsigned short* q = p.out_rec + rm.row * p.rec_row + (n >> 5) * 64 + (n & 31);
+        q[0] = hb;
+        q[32] = f2bf(v - bf2f(hb));
+    }
+    if (!p.out) return;
     if (p.out_dtype == SKIMI_F32) {
         ((float*)p.out)[o] = v;
         if (p.out2) ((unsigned short*)p.out2)[o2] = f2bf(v);
@@ -210,6 +236,8 @@ __device__ __forceinline__ void store_four(const GemmArgs& p, const RowMap& rm, 
         o = pix * p.ldo + co;
         o2 = pix * p.ldo2 + co;
     }
+    if (p.out_rec) store_rec4(p, rm.row, n, v[0], v[1], v[2], v[3]);
+    if (!p.out) return;
     bf16x4 hb;
 #pragma unroll
     for (int k = 0; k < 4; ++k) hb[k] = (short)f2bf(v[k]);

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4_kernel(const GemmArgs p, con
     const bool relu_ok = (p.act == SKIMI_ACT_NONE || p.act == SKIMI_ACT_RELU) &&
                          (p.post_act == SKIMI_ACT_NONE || p.post_act == SKIMI_ACT_RELU);
     const bool fast = p.vec4 && p.store_mode == 0 && p.out_rpb == 0 && p.out_off == 0 && p.out2 == nullptr &&
-                      p.out_dtype == SKIMI_F32 && p.gamma == nullptr && p.resid2 == nullptr && relu_ok &&
+                      p.out_dtype == SKIMI_F32 && p.gamma == nullptr && relu_ok && (p.resid != nullptr || p.resid2 == nullptr) &&
                       (p.resid == nullptr || (p.resid_dtype == SKIMI_F32 && p.resid_rpb == 0 && p.resid_off == 0)) &&
                       m0 + BM <= p.M && n0 + BN <= p.N;   // block-uniform
     if (fast) {
@@ -360,8 +360,9 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4_kernel(const GemmArgs p, con
         float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias) bs = *reinterpret_cast<const float4*>(p.bias + n);
         const float* rs = reinterpret_cast<const float*>(p.resid);
+        const float* rs2 = reinterpret_cast<const float*>(p.resid2);
         float* out = reinterpret_cast<float*>(p.out);
-#define SKIMI_X3_EPI_PASS(HAS_RES)                                                                                 \
+#define SKIMI_X3_EPI_PASS(HAS_RES, HAS_OUT, HAS_REC)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r)               \
             stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + j * 32 + l31] = acc[i][j][r];                           \
@@ -369,25 +370,38 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4_kernel(const GemmArgs p, con
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                                        \
         _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                   \
             const long mrow = m0 + wr * 128 + i * 32 + half * 16 + lh;                                             \
-            float4 v[8], rr[8];                                                                                    \
+            float4 v[8], rr[8], r2[8];                                                                             \
             _Pragma("unroll") for (int it = 0; it < 8; ++it)                                                       \
                 v[it] = *reinterpret_cast<const float4*>(&stg[(half * 16 + it * 2 + lh) * 128 + 4 * (lane & 31)]); \
             if (HAS_RES) _Pragma("unroll") for (int it = 0; it < 8; ++it)                                          \
                 rr[it] = *reinterpret_cast<const float4*>(rs + (mrow + it * 2) * p.ldr + n);                       \
+            if (HAS_RES == 2) _Pragma("unroll") for (int it = 0; it < 8; ++it)                                     \
+                r2[it] = *reinterpret_cast<const float4*>(rs2 + (mrow + it * 2) * p.ldr2 + n);                     \
             _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                     \
                 float4 y = make_float4(fmaxf(v[it].x + bs.x, lo1), fmaxf(v[it].y + bs.y, lo1),                     \
                                        fmaxf(v[it].z + bs.z, lo1), fmaxf(v[it].w + bs.w, lo1));                    \
                 if (HAS_RES) { y.x += rr[it].x; y.y += rr[it].y; y.z += rr[it].z; y.w += rr[it].w; }               \
+                if (HAS_RES == 2) { y.x += r2[it].x; y.y += r2[it].y; y.z += r2[it].z; y.w += r2[it].w; }          \
                 y = make_float4(fmaxf(y.x, lo2), fmaxf(y.y, lo2), fmaxf(y.z, lo2), fmaxf(y.w, lo2));               \
-                *reinterpret_cast<float4*>(out + (mrow + it * 2) * p.ldo + n) = y;                                 \
+                if (HAS_OUT) *reinterpret_cast<float4*>(out + (mrow + it * 2) * p.ldo + n) = y;                    \
+                if (HAS_REC) store_rec4(p, mrow + it * 2, n, y.x, y.y, y.z, y.w);                                  \
             }                                                                                                      \
         }                                                                                                          \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                                        \
     }
-        if (rs) {
-            SKIMI_X3_EPI_PASS(true)
-        } else {
-            SKIMI_X3_EPI_PASS(false)
+        // compile-time variants: a uniform branch inside the unrolled passes would cost a vmcnt(0) per store
+        const int variant = (rs2 ? 8 : rs ? 4 : 0) | (out ? 2 : 0) | (p.out_rec ? 1 : 0);
+        switch (variant) {
+            case 11: SKIMI_X3_EPI_PASS(2, true, true) break;
+            case 10: SKIMI_X3_EPI_PASS(2, true, false) break;
+            case 9: SKIMI_X3_EPI_PASS(2, false, true) break;
+            case 7: SKIMI_X3_EPI_PASS(1, true, true) break;
+            case 6: SKIMI_X3_EPI_PASS(1, true, false) break;
+            case 5: SKIMI_X3_EPI_PASS(1, false, true) break;
+            case 3: SKIMI_X3_EPI_PASS(0, true, true) break;
+            case 2: SKIMI_X3_EPI_PASS(0, true, false) break;
+            case 1: SKIMI_X3_EPI_PASS(0, false, true) break;
+            default: break;
         }
 #undef SKIMI_X3_EPI_PASS
         return;
@@ -624,7 +638,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4n_kernel(const GemmArgs p, co
     const bool relu_ok = (p.act == SKIMI_ACT_NONE || p.act == SKIMI_ACT_RELU) &&
                          (p.post_act == SKIMI_ACT_NONE || p.post_act == SKIMI_ACT_RELU);
     const bool fast = p.vec4 && p.store_mode == 0 && p.out_rpb == 0 && p.out_off == 0 && p.out2 == nullptr &&
-                      p.out_dtype == SKIMI_F32 && p.gamma == nullptr && p.resid2 == nullptr && relu_ok &&
+                      p.out_dtype == SKIMI_F32 && p.gamma == nullptr && relu_ok && (p.resid != nullptr || p.resid2 == nullptr) &&
                       (p.resid == nullptr || (p.resid_dtype == SKIMI_F32 && p.resid_rpb == 0 && p.resid_off == 0)) &&
                       m0 + BM <= p.M && n0 + BN <= p.N;   // block-uniform
     if (fast) {
@@ -633,32 +647,45 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4n_kernel(const GemmArgs p, co
         float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.bias) bs = *reinterpret_cast<const float4*>(p.bias + n);
         const float* rs = reinterpret_cast<const float*>(p.resid);
+        const float* rs2 = reinterpret_cast<const float*>(p.resid2);
         float* out = reinterpret_cast<float*>(p.out);
-#define SKIMI_X3N_EPI_PASS(HAS_RES)                                                                                \
+#define SKIMI_X3N_EPI_PASS(HAS_RES, HAS_OUT, HAS_REC)                                                                                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r)               \
             stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + j * 32 + l31] = acc[i][j][r];                            \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                     \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                                        \
         const long mrow = m0 + wr * 128 + i * 32 + (lane >> 4);                                                    \
-        float4 v[8], rr[8];                                                                                        \
+        float4 v[8], rr[8], r2[8];                                                                                 \
         _Pragma("unroll") for (int it = 0; it < 8; ++it)                                                           \
             v[it] = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + 4 * (lane & 15)]);         \
         if (HAS_RES) _Pragma("unroll") for (int it = 0; it < 8; ++it)                                              \
             rr[it] = *reinterpret_cast<const float4*>(rs + (mrow + it * 4) * p.ldr + n);                           \
+        if (HAS_RES == 2) _Pragma("unroll") for (int it = 0; it < 8; ++it)                                         \
+            r2[it] = *reinterpret_cast<const float4*>(rs2 + (mrow + it * 4) * p.ldr2 + n);                         \
         _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                         \
             float4 y = make_float4(fmaxf(v[it].x + bs.x, lo1), fmaxf(v[it].y + bs.y, lo1),                         \
                                    fmaxf(v[it].z + bs.z, lo1), fmaxf(v[it].w + bs.w, lo1));                        \
             if (HAS_RES) { y.x += rr[it].x; y.y += rr[it].y; y.z += rr[it].z; y.w += rr[it].w; }                   \
+            if (HAS_RES == 2) { y.x += r2[it].x; y.y += r2[it].y; y.z += r2[it].z; y.w += r2[it].w; }              \
             y = make_float4(fmaxf(y.x, lo2), fmaxf(y.y, lo2), fmaxf(y.z, lo2), fmaxf(y.w, lo2));                   \
-            *reinterpret_cast<float4*>(out + (mrow + it * 4) * p.ldo + n) = y;                                     \
+            if (HAS_OUT) *reinterpret_cast<float4*>(out + (mrow + it * 4) * p.ldo + n) = y;                        \
+            if (HAS_REC) store_rec4(p, mrow + it * 4, n, y.x, y.y, y.z, y.w);                                      \
         }                                                                                                          \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                                        \
     }
-        if (rs) {
-            SKIMI_X3N_EPI_PASS(true)
-        } else {
-            SKIMI_X3N_EPI_PASS(false)
+        const int variant = (rs2 ? 8 : rs ? 4 : 0) | (out ? 2 : 0) | (p.out_rec ? 1 : 0);
+        switch (variant) {
+            case 11: SKIMI_X3N_EPI_PASS(2, true, true) break;
+            case 10: SKIMI_X3N_EPI_PASS(2, true, false) break;
+            case 9: SKIMI_X3N_EPI_PASS(2, false, true) break;
+            case 7: SKIMI_X3N_EPI_PASS(1, true, true) break;
+            case 6: SKIMI_X3N_EPI_PASS(1, true, false) break;
+            case 5: SKIMI_X3N_EPI_PASS(1, false, true) break;
+            case 3: SKIMI_X3N_EPI_PASS(0, true, true) break;
+            case 2: SKIMI_X3N_EPI_PASS(0, true, false) break;
+            case 1: SKIMI_X3N_EPI_PASS(0, false, true) break;
+            default: break;
         }
 #undef SKIMI_X3N_EPI_PASS
         return;

@@ -289,6 +289,7 @@ struct Packer {
             const std::string rp = p + ".scratch.refinenet" + std::to_string(r + 1);
             FusionW& f = d.ref[r];
             f.out_conv = linear(rp + ".out_conv", features, features, prec);
+            if (!rc && prec == SKIMI_PREC_BF16X3 && features % 32 == 0) add_records(f.out_conv);
             f.has_r1 = r != 3;
             if (f.has_r1) {
                 f.r1c1 = conv(rp + ".resConfUnit1.conv1", features, features, 3, 1, 1, prec, true);
@@ -337,7 +338,7 @@ struct Ctx {
         // LDS-DMA bf16x3 kernel (released right after the launch is enqueued: stream order keeps
         // later users of that memory behind it)
         const size_t mk = ar.mark();
-        if (d.W_split != nullptr) {
+        if (d.W_split != nullptr && d.a_dtype != SKIMI_BF16X3_REC) {
             d.x3_scratch_bytes = gemm_x3dma_scratch_bytes(&d);
             d.x3_scratch = ar.alloc(d.x3_scratch_bytes);
         }
@@ -435,6 +436,25 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
     int ww[4] = {pw * 4, pw * 2, pw, (pw - 1) / 2 + 1};
     void* rn[4];
     for (int i = 0; i < 4; ++i) rn[i] = c.ar.alloc((size_t)F * hh[i] * ww[i] * feat * es);
+    // Levels whose feat -> feat convs run on the LDS-DMA bf16x3 kernel hand their activations over as
+    // operand records ([feat/32][hi 32 | lo 32] per pixel, + zero page) written by the producing
+    // epilogue: no split pass, and no fp32 copy at all where the only reader is the next conv.
+    auto rec_bytes = [&](int lvl) { return (size_t)F * hh[lvl] * ww[lvl] * feat * 4 + 256; };
+    auto takes_records = [&](const Lin& L, const ConvW* cw, int lvl) {
+        if (adt != SKIMI_F32 || feat % 32 != 0 || L.w_split == nullptr) return false;
+        char* fake = (char*)(uintptr_t)0x10000000;   // eligibility looks at alignment and distances only
+        auto d = c.desc(L, fake, SKIMI_BF16X3_REC, feat, F * hh[lvl] * ww[lvl], fake, adt, L.N);
+        if (cw) c.conv_geom(d, *cw, F, hh[lvl], ww[lvl], hh[lvl], ww[lvl]);
+        d.x3_scratch = fake + rec_bytes(lvl) - 256;
+        d.x3_scratch_bytes = 256;
+        return gemm_x3dma_eligible(&d);
+    };
+    bool use_rec[4];
+    char* rn_rec[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i) {
+        use_rec[i] = takes_records(w.ref[i].r2c1.lin, &w.ref[i].r2c1, i);
+        if (use_rec[i]) rn_rec[i] = (char*)c.ar.alloc(rec_bytes(i));
+    }
     {
         const size_t mk2 = c.ar.mark();
         void* lnb = c.ar.alloc((size_t)F * np * D * es);
@@ -472,6 +492,7 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
                 auto d = c.desc(w.rn[i].lin, t1, adt, w.oc[i], F * hh[i] * ww[i], rn[i], adt, feat);
                 c.conv_geom(d, w.rn[i], F, hh[i], ww[i], hh[i], ww[i]);
                 d.act = SKIMI_ACT_RELU;
+                d.out_records = rn_rec[i];
                 c.gemm(d);
             }
             c.ar.release(mk3);
@@ -486,34 +507,48 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
         const int h0 = hh[r], w0 = ww[r];
         const int M = F * h0 * w0;
         const size_t bytes = (size_t)M * feat * es;
-        void* cur;   // relu(input of resConfUnit2)
-        void* tmp = c.ar.alloc(bytes);
+        const bool recs = use_rec[r];
+        // a feat -> feat conv of this level: input as fp32 rows or as records
+        auto conv_in = [&](const ConvW& cw, const void* in_f32, char* in_rec, void* out_f32, char* out_rec) {
+            auto d = c.desc(cw.lin, recs ? (const void*)in_rec : in_f32, recs ? SKIMI_BF16X3_REC : adt, feat, M, out_f32, adt, feat);
+            c.conv_geom(d, cw, F, h0, w0, h0, w0);
+            if (recs) {
+                d.x3_scratch = in_rec + rec_bytes(r) - 256;
+                d.x3_scratch_bytes = 256;
+            }
+            d.out_records = out_rec;
+            return d;
+        };
+        void* cur;                  // relu(input of resConfUnit2)
+        char* cur_rec = nullptr;
+        void* tmp = recs ? nullptr : c.ar.alloc(bytes);
+        char* tmp_rec = recs ? (char*)c.ar.alloc(rec_bytes(r)) : nullptr;
         if (f.has_r1) {
             // res = RCU1(layer_rn): conv2(relu(conv1(relu(x)))) + relu(x); output = prev + res;
             // RCU2's in-place ReLU then rewrites output -> store relu(prev + res) directly
             cur = c.ar.alloc(bytes);
-            auto d1 = c.desc(f.r1c1.lin, rn[r], adt, feat, M, tmp, adt, feat);
-            c.conv_geom(d1, f.r1c1, F, h0, w0, h0, w0);
+            if (recs) cur_rec = (char*)c.ar.alloc(rec_bytes(r));
+            auto d1 = conv_in(f.r1c1, rn[r], rn_rec[r], tmp, tmp_rec);
             d1.act = SKIMI_ACT_RELU;
             c.gemm(d1);
-            auto d2 = c.desc(f.r1c2.lin, tmp, adt, feat, M, cur, adt, feat);
-            c.conv_geom(d2, f.r1c2, F, h0, w0, h0, w0);
+            auto d2 = conv_in(f.r1c2, tmp, tmp_rec, cur, cur_rec);
             d2.resid = rn[r]; d2.ldr = feat; d2.resid_dtype = adt;
             d2.resid2 = prev; d2.ldr2 = feat;
             d2.post_act = SKIMI_ACT_RELU;
             c.gemm(d2);
         } else {
             cur = rn[r];
+            cur_rec = rn_rec[r];
         }
-        // RCU2(cur): conv2(relu(conv1(cur))) + cur
-        void* u = c.ar.alloc(bytes);
+        // RCU2(cur): conv2(relu(conv1(cur))) + cur; its result is read by the 1x1 out_conv only
+        const bool u_recs = recs && takes_records(f.out_conv, nullptr, r);
+        void* u = u_recs ? nullptr : c.ar.alloc(bytes);
+        char* u_rec = u_recs ? (char*)c.ar.alloc(rec_bytes(r)) : nullptr;
         {
-            auto d1 = c.desc(f.r2c1.lin, cur, adt, feat, M, tmp, adt, feat);
-            c.conv_geom(d1, f.r2c1, F, h0, w0, h0, w0);
+            auto d1 = conv_in(f.r2c1, cur, cur_rec, tmp, tmp_rec);
             d1.act = SKIMI_ACT_RELU;
             c.gemm(d1);
-            auto d2 = c.desc(f.r2c2.lin, tmp, adt, feat, M, u, adt, feat);
-            c.conv_geom(d2, f.r2c2, F, h0, w0, h0, w0);
+            auto d2 = conv_in(f.r2c2, tmp, tmp_rec, u, u_rec);
             d2.resid = cur; d2.ldr = feat; d2.resid_dtype = adt;
             c.gemm(d2);
         }
@@ -524,7 +559,11 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
         const int h1 = r > 0 ? hh[r - 1] : 2 * h0, w1 = r > 0 ? ww[r - 1] : 2 * w0;
         void* olow = c.ar.alloc(bytes);
         {
-            auto d = c.desc(f.out_conv, u, adt, feat, M, olow, adt, feat);
+            auto d = c.desc(f.out_conv, u_recs ? (const void*)u_rec : u, u_recs ? SKIMI_BF16X3_REC : adt, feat, M, olow, adt, feat);
+            if (u_recs) {
+                d.x3_scratch = u_rec + rec_bytes(r) - 256;
+                d.x3_scratch_bytes = 256;
+            }
             c.gemm(d);
         }
         // The last level's upsampled map is read by output_conv1 only: when that conv runs on the

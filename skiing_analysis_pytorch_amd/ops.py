@@ -27,18 +27,30 @@ def _require_cuda(*ts):
 
 def gemm(a, w, *, prec=PREC_BF16X3, bias=None, gamma=None, resid=None, act=ACT_NONE, out=None,
          out_dtype=torch.float32, conv=None, resid_map=None, pixel_shuffle=None, splitk_scratch=None,
-         force_splitk=0, M=None, lda=None, w_split=None, x3_scratch=None):
+         force_splitk=0, M=None, lda=None, w_split=None, x3_scratch=None, a_records=None, out_records=None,
+         records_only=False, post_act=ACT_NONE):
     """out = epilogue(gather(a) @ w.T).  a: [rows, lda] (f32|bf16), w: [N, K].
 
     conv = dict(N,H,W,C,KH,KW,stride,pad,dil,OH,OW) selects the implicit-im2col gather;
-    resid_map = (rows_per_batch, batch_stride, row_off); pixel_shuffle = (s, Cout, N, H, W)."""
-    _require_cuda(a, w, bias, gamma, resid, out)
+    resid_map = (rows_per_batch, batch_stride, row_off); pixel_shuffle = (s, Cout, N, H, W).
+    out_records = a `records_buffer(M, N)`: the result also as bf16x3 records (+ zero page) for a
+    following `gemm(None, ..., a_records=that buffer)` (its [rows, C] shape comes through `conv`, or
+    `M` and `lda` for plain rows); records_only: no fp32 result at all (returns None).
+    post_act: activation applied after the residual add."""
+    _require_cuda(w, bias, gamma, resid, out)
     d = GemmDesc()
     N, K = w.shape
     d.N, d.K = N, K
-    d.A, d.W = ptr(a), ptr(w)
-    d.a_dtype, d.w_dtype = _dt(a), _dt(w)
-    d.lda = lda if lda is not None else a.stride(-2) if a.dim() >= 2 else a.shape[-1]
+    d.W, d.w_dtype = ptr(w), _dt(w)
+    if a_records is not None:
+        _require_cuda(a_records)
+        d.A, d.a_dtype = ptr(a_records), _lib.BF16X3_REC
+        d.lda = lda if lda is not None else (conv["C"] if conv is not None else K)
+    else:
+        _require_cuda(a)
+        d.A, d.a_dtype = ptr(a), _dt(a)
+        d.lda = lda if lda is not None else a.stride(-2) if a.dim() >= 2 else a.shape[-1]
+    dev = w.device
     d.ldw = w.stride(0)
     d.prec = prec
     if conv is not None:
@@ -49,32 +61,44 @@ def gemm(a, w, *, prec=PREC_BF16X3, bias=None, gamma=None, resid=None, act=ACT_N
         d.M = d.cN * d.OH * d.OW
     else:
         d.M = M if M is not None else a.shape[0]
-    if pixel_shuffle is not None:
+    if records_only:
+        assert out is None and out_records is not None and pixel_shuffle is None
+        d.out_dtype = _lib.F32
+    elif pixel_shuffle is not None:
         s, cout, n_img, h, w_ = pixel_shuffle
         d.store_mode, d.ps_s, d.ps_C = 1, s, cout
         d.cN, d.cH, d.cW = n_img, h, w_
         if out is None:
-            out = torch.empty((n_img, h * s, w_ * s, cout), dtype=out_dtype, device=a.device)
+            out = torch.empty((n_img, h * s, w_ * s, cout), dtype=out_dtype, device=dev)
         d.ldo = out.stride(-2)
     else:
         if out is None:
-            out = torch.empty((d.M, N), dtype=out_dtype, device=a.device)
+            out = torch.empty((d.M, N), dtype=out_dtype, device=dev)
         d.ldo = out.stride(-2)
-    d.out, d.out_dtype = ptr(out), _dt(out)
+    if not records_only:
+        d.out, d.out_dtype = ptr(out), _dt(out)
     d.bias, d.gamma, d.resid = ptr(bias), ptr(gamma), ptr(resid)
     if resid is not None:
         d.ldr = resid.stride(-2)
     if resid_map is not None:
         d.resid_rows_per_batch, d.resid_batch_stride, d.resid_row_off = resid_map
     d.act = act
+    d.post_act = post_act
     if splitk_scratch is not None:
         d.splitk_scratch = ptr(splitk_scratch)
         d.splitk_scratch_bytes = splitk_scratch.numel() * splitk_scratch.element_size()
     d.force_splitk = force_splitk
     if w_split is not None:
         d.W_split = ptr(w_split)
-        d.x3_scratch = ptr(x3_scratch)
-        d.x3_scratch_bytes = x3_scratch.numel() * x3_scratch.element_size()
+        if a_records is not None:   # the zero page behind the records
+            d.x3_scratch = ptr(a_records) + a_records.numel() * 2 - 256
+            d.x3_scratch_bytes = 256
+        else:
+            d.x3_scratch = ptr(x3_scratch)
+            d.x3_scratch_bytes = x3_scratch.numel() * x3_scratch.element_size()
+    if out_records is not None:
+        _require_cuda(out_records)
+        d.out_records = ptr(out_records)
     check(lib().skimi_gemm(C.byref(d), _lib.current_stream()), "skimi_gemm")
     return out
 
@@ -134,6 +158,11 @@ def split_records(x):
     out = torch.empty((rows, (Cc + 31) // 32, 2, 32), dtype=torch.bfloat16, device=x.device)
     check(lib().skimi_split_records(ptr(x), x.stride(0), rows, Cc, ptr(out), _lib.current_stream()), "skimi_split_records")
     return out
+
+
+def records_buffer(rows, Cc, device="cuda"):
+    """bf16 buffer for [rows, Cc] as bf16x3 records + the 256-byte zero page behind them."""
+    return torch.empty(rows * ((Cc + 31) // 32) * 64 + 128, dtype=torch.bfloat16, device=device)
 
 
 def x3_scratch_numel(rows, Cc):

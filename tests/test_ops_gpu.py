@@ -397,6 +397,38 @@ def test_gemm_x3dma_conv(cfg, x3_small_shapes):
     assert _rel(out, ref.permute(0, 2, 3, 1).reshape(-1, Co)) < 2e-5
 
 
+@pytest.mark.parametrize("Co", [256, 128])
+def test_gemm_records_chain(Co, x3_small_shapes):
+    """conv -> conv with the intermediate handed over as bf16x3 records written by the first conv's epilogue
+    (out_records, with and without the fp32 copy) instead of fp32 + a split pass: same results."""
+    n, H, W_, Cc = 2, 70, 65, 64           # 9100 rows: interior tiles + a ragged last one
+    x = _rand(n, H, W_, Cc, seed=91)
+    w1 = _rand(Co, Cc, 3, 3, seed=92, scale=1 / math.sqrt(Cc * 9))
+    w2 = _rand(256, Co, 3, 3, seed=93, scale=1 / math.sqrt(Co * 9))
+    b1, b2 = _rand(Co, seed=94), _rand(256, seed=95)
+    r = _rand(n * H * W_, Co, seed=96)
+    ref1 = F.relu(F.relu(F.conv2d(x.permute(0, 3, 1, 2), w1, b1, padding=1)).permute(0, 2, 3, 1).reshape(-1, Co) + r)
+    ref2 = F.conv2d(ref1.reshape(n, H, W_, Co).permute(0, 3, 1, 2), w2, b2, padding=1).permute(0, 2, 3, 1).reshape(-1, 256)
+    pack = lambda w: w.reshape(w.shape[0], w.shape[1] // 32, 32, 3, 3).permute(0, 1, 3, 4, 2).reshape(w.shape[0], -1).contiguous()
+    wp1, wp2 = pack(w1), pack(w2)
+    conv1 = dict(N=n, H=H, W=W_, C=Cc, KH=3, KW=3, stride=1, pad=1, dil=1, OH=H, OW=W_, slice_major=True)
+    conv2 = dict(conv1, C=Co)
+    from skiing_analysis_pytorch_amd._lib import ACT_RELU as RELU
+    for keep_fp32 in (True, False):
+        rec = ops.records_buffer(n * H * W_, Co)
+        rec.fill_(float("nan"))
+        sc = torch.empty(ops.x3_scratch_numel(n * H * W_, Cc), dtype=torch.float32, device=DEV)
+        out1 = torch.empty(n * H * W_, Co, device=DEV) if keep_fp32 else None
+        y1 = ops.gemm(x.reshape(-1, Cc), wp1, prec=PREC_BF16X3, bias=b1, act=RELU, resid=r, post_act=RELU, conv=conv1,
+                      w_split=ops.split_records(wp1), x3_scratch=sc, out=out1, out_records=rec, records_only=not keep_fp32)
+        if keep_fp32:
+            assert _rel(y1, ref1) < 2e-5
+            assert torch.equal(rec[:-128].reshape(-1, Co // 32, 2, 32), ops.split_records(y1))
+        assert (rec[-128:] == 0).all()
+        y2 = ops.gemm(None, wp2, prec=PREC_BF16X3, bias=b2, conv=conv2, w_split=ops.split_records(wp2), a_records=rec)
+        assert _rel(y2, ref2) < 3e-5
+
+
 def test_gemm_x3dma_pixel_shuffle(x3_small_shapes):
     n, H, W_, Cc, Co, s = 3, 37, 37, 256, 256, 2
     x = _rand(n, H, W_, Cc, seed=88)
