@@ -469,7 +469,7 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     }
     SKIMI_CHECK_ARG(d->a_dtype != SKIMI_BF16X3_REC,
                     "skimi_gemm: A given as bf16x3 records, but the launch does not qualify for the LDS-DMA kernel "
-                    "(M=%d N=%d: needs W_split, M >= 4096, N >= 96, >= 200 tiles of 256 rows, a zero page behind A)", d->M, d->N);
+                    "(M=%d N=%d: needs W_split, M >= 4096, N >= 96, most of a chip's worth of 256-row tiles (>= 160), a zero page behind A)", d->M, d->N);
 
     // large bf16 x bf16 plain-row shapes: 256x256 tiles staged by LDS-DMA (gemm256.hip)
     if (force_splitk <= 0 && gemm256_eligible(d)) {

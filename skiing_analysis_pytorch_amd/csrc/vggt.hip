@@ -279,7 +279,10 @@ struct Packer {
         d.feature_only = feature_only;
         for (int i = 0; i < 4; ++i) d.oc[i] = oc[i];
         d.norm = ln(p + ".norm", D);
-        for (int i = 0; i < 4; ++i) d.proj[i] = linear(p + ".projects." + std::to_string(i), oc[i], D, prec);
+        for (int i = 0; i < 4; ++i) {
+            d.proj[i] = linear(p + ".projects." + std::to_string(i), oc[i], D, prec);
+            if (!rc && prec == SKIMI_PREC_BF16X3 && oc[i] >= 512 && D % 32 == 0) add_records(d.proj[i]);
+        }
         d.rs0 = convT(p + ".resize_layers.0", oc[0], 4, prec);
         d.rs1 = convT(p + ".resize_layers.1", oc[1], 2, prec);
         d.rs3 = conv(p + ".resize_layers.3", oc[3], oc[3], 3, 2, 1, prec, true);

@@ -336,7 +336,7 @@ def test_gelu_epilogue_matches_erf_gelu():
 
 @pytest.fixture
 def x3_small_shapes(monkeypatch):
-    """The LDS-DMA bf16x3 kernels are only picked for launches of >= 200 tiles; let test shapes through."""
+    """The LDS-DMA bf16x3 kernels are only picked for launches of >= 160 tiles; let test shapes through."""
     monkeypatch.setenv("SKIMI_X3_MIN_TILES", "1")
 
 

@@ -142,7 +142,7 @@ def test_vggt_fullsize_fp32_mode_vs_oracle(H, W, head, monkeypatch):
     relc = (out[ckey].cpu() - ref[ckey]).abs() / (ref[ckey].abs() + 1.0)
     assert relc.max().item() < 1e-3
     # The same forward with the DPT convs forced onto the LDS-DMA bf16x3 kernels (picked on their own only
-    # for >= 200 tiles of 256 rows, i.e. the 32-frame bench batch): activations handed from conv to conv
+    # for most of a chip's worth of 256-row tiles (>= 160), i.e. the 32-frame bench batch): activations handed from conv to conv
     # as bf16x3 records, upsample -> records, two-residual epilogue.
     monkeypatch.setenv("SKIMI_X3_MIN_TILES", "1")
     out2 = m(img.cuda(), want={"camera", head})
