@@ -2,12 +2,27 @@
 usage: make_profile_summary.py <kernel_trace.csv> <bench_line.json> <steps in trace> <out.md>"""
 import csv, json, collections, sys
 trace, linef, NS, outp = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-rows = list(csv.DictReader(open(trace)))
+def load_rows(path):
+    """[(kernel name, grid_x, workgroup_x, duration ns)] from a rocprofv3 kernel trace: the CSV of
+    --output-format csv, or the rocpd sqlite database that rocprofv3 writes by default."""
+    if path.endswith(".db"):
+        import sqlite3
+        cur = sqlite3.connect(path).cursor()
+        tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+        kd = [t for t in tabs if t.startswith('rocpd_kernel_dispatch')][0]
+        ks = [t for t in tabs if t.startswith('rocpd_info_kernel_symbol')][0]
+        cols = [r[1] for r in cur.execute(f"pragma table_info({ks})")]
+        names = dict(cur.execute(f"select id, {'display_name' if 'display_name' in cols else 'kernel_name'} from {ks}"))
+        return [(names[k], str(gx), str(wx), e - s0)
+                for k, s0, e, gx, wx in cur.execute(f"select kernel_id, start, end, grid_size_x, workgroup_size_x from {kd}")]
+    return [(r['Kernel_Name'], r['Grid_Size_X'], r['Workgroup_Size_X'], int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+            for r in csv.DictReader(open(path))]
+
+
 g = collections.defaultdict(lambda: [0, 0]); byk = collections.defaultdict(lambda: [0, 0]); tot = 0
-for r in rows:
-    n = r['Kernel_Name'].replace('void ', '').replace('skimi::', '').split('(')[0]
-    d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
-    k = (n, r['Grid_Size_X'], r['Workgroup_Size_X'])
+for name, gx, wx, d in load_rows(trace):
+    n = name.replace('void ', '').replace('skimi::', '').split('(')[0]
+    k = (n, gx, wx)
     g[k][0] += d; g[k][1] += 1; byk[n][0] += d; byk[n][1] += 1; tot += d
 line = json.load(open(linef))
 out = []
@@ -20,7 +35,7 @@ for n, v in sorted(byk.items(), key=lambda kv: -kv[1][0])[:24]:
 rf = line['roofline']
 out.append(f"\nUn-profiled bench line of the same build (`profiles/r01_bench_line.json`, full default run incl. the CPU legs):")
 out.append(f"- value {line['value']:.2f} frames/s, {line['ms_per_step']:.1f} ms/step (4 time steps), whole path {line['whole_path_tflops']:.0f} TFLOP/s")
-out.append(f"- roofline: {rf['kernel']}: {rf['achieved']:.0f} TFLOP/s = {100*rf['frac']:.1f}% of {rf['peak']:.0f} (avg launch {rf['avg_launch_us']:.0f} us over {rf['launches']} launches, HIP events on the launch stream inside bench.py); HBM traffic {rf['traffic']/1e6:.0f} MB per launch (`profiles/r01_attn_traffic.json`: FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes) against {4*10992*1024*2*4/1e6:.0f} MB algorithmic (q, k, v read once, o written once).  Run-to-run: fresh boxes differ by about +-2 % (clocks); 958-970 TFLOP/s were measured on others.")
+out.append(f"- roofline: {rf['kernel']}: {rf['achieved']:.0f} TFLOP/s = {100*rf['frac']:.1f}% of {rf['peak']:.0f} (avg launch {rf['avg_launch_us']:.0f} us over {rf['launches']} launches, HIP events on the launch stream inside bench.py); HBM traffic {rf['traffic']/1e6:.0f} MB per launch (`profiles/r01_attn_traffic.json`: FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes) against {4*10992*1024*2*4/1e6:.0f} MB algorithmic (q, k, v read once, o written once).  Run-to-run: fresh boxes differ by several % (clocks, thermal state): 16.4-18.1 frames/s and 923-982 TFLOP/s were measured for this build.")
 cb = line['cpu_baseline']
 out.append(f"- cpu_baseline: {cb['value']:.4f} frames/s on {cb['cores']} cores ({cb['sample']})")
 vp = line.get('vp3d')
@@ -41,6 +56,6 @@ for k, v in sorted(g.items(), key=lambda kv: -kv[1][0]):
         out.append(f"| {v[1]/NS:.0f} | {k[1]} = {wg} WG x {k[2]} | {shape} | {v[0]/v[1]/1e3:.1f} |")
 if ga:
     out.append(f"\nThe {ga[0]/ga[1]/1e3:.0f} us of the global-attention launches under rocprofv3 against the {rf['avg_launch_us']:.0f} us that bench.py measures un-profiled (a different box; profiled passes also clock a few % lower, MI355X_MICROARCH.md cycle-constants note 2); {rf['flops_per_launch']/1e9:.1f} GFLOP per launch -> {rf['flops_per_launch']/(ga[0]/ga[1])/1e3:.0f} (profiled) / {rf['achieved']:.0f} (un-profiled) TFLOP/s.")
-out.append("\nGEMM shapes behind the `gemm256*` rows (M = 4 x 10992 = 43968 token rows): `gemm256_kernel<3,1>` qkv 1024->3072 (bias -> bf16), `gemm256pp_kernel<3>` fc1 1024->4096 (bias, GELU -> bf16), `gemm256pp_kernel<2>` proj 1024->1024 and fc2 4096->1024 (bias, LayerScale, fp32 residual).  `gemm_x3dma_kernel`, `gemm_kernel<...,3,float,float>` and `conv_direct_n32_kernel` are the fp32-accurate (bf16x3) convolutions of the depth and point DPT heads.")
+out.append("\nGEMM shapes behind the `gemm256*` rows (M = 4 x 10992 = 43968 token rows; template argument = epilogue): `gemm256w4_kernel<1>` qkv 1024->3072 (bias -> bf16) and `gemm256w4_kernel<2>` fc2 4096->1024 (bias, LayerScale, fp32 residual) on the single-stream 4-wave loop; `gemm256pp_kernel<3,1>` fc1 1024->4096 (bias, GELU -> bf16) and `gemm256pp_kernel<2,1>` proj 1024->1024 (residual epilogue) on the 8-wave ping-pong loop.  `gemm_x3w4_kernel<a_mode>` / `gemm_x3w4n_kernel` (256- / 128-column tiles), `gemm_kernel<...,3,float,float>` and `conv_direct_n32_kernel` are the fp32-accurate (bf16x3) convolutions of the depth and point DPT heads; `bilinear_ac_planes_kernel` is the upsample that writes their bf16 hi|lo operands directly.")
 open(outp, 'w').write("\n".join(out) + "\n")
 print("\n".join(out)[:2500])
