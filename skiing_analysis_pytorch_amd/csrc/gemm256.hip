@@ -496,14 +496,6 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const GemmArgs p) {
     tile_coords256(p, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
     const int nkt = p.K / BK;
-    // experiment: stagger the first round of workgroups (dbg bits 8..15 = units of ~0.85 us per
-    // step; bits 16..17 = what to stagger by: 0 XCD, 1 CU group of 8 within the XCD, 2 both)
-    if ((p.dbg >> 8) && blockIdx.x < 256) {
-        const int unit = (p.dbg >> 8) & 255, mode = (p.dbg >> 16) & 3;
-        const int step = mode == 0 ? (blockIdx.x & 7) : mode == 1 ? ((blockIdx.x >> 3) & 3) * 2 : (blockIdx.x & 7) + ((blockIdx.x >> 3) & 3) * 8;
-        for (int i = 0; i < step * unit; ++i) __builtin_amdgcn_s_sleep(32);
-    }
-
     // DMA: a piece is 16 wave-instructions (8 rows x 128 B each); this wave issues 4*wave + j
     const unsigned short* src[4][4];   // [q][j]
 #pragma unroll

@@ -14,8 +14,7 @@ for (n,H,W,C,Co,k) in [(32,148,148,256,256,3),(32,74,74,256,256,3),(8,296,296,25
     o=torch.empty(n*H*W,Co,device=D)
     t=timeit(lambda: ops.gemm(x,w,prec=PREC_BF16X3,conv=conv,out=o),iters=5)
     ws=ops.split_records(w); sc=torch.empty(ops.x3_scratch_numel(x.shape[0],C),device=D)
-    t2=float("nan")
     t4=timeit(lambda: ops.gemm(x,w,prec=PREC_BF16X3,conv=conv,out=o,w_split=ws,x3_scratch=sc),iters=5)
     xb=x.to(torch.bfloat16); wb=w.to(torch.bfloat16); ob=torch.empty(n*H*W,Co,device=D,dtype=torch.bfloat16)
     t3=timeit(lambda: ops.gemm(xb,wb,prec=PREC_BF16,conv=conv,out=ob),iters=5)
-    print(f"conv{k} {H}x{W} {C}->{Co}: generic x3 {t*1e6:.0f} us {fl/t/1e12:.0f} TF/s | x3dma 8-wave {t2*1e6:.0f} us {fl/t2/1e12:.0f} TF/s | single-stream {t4*1e6:.0f} us {fl/t4/1e12:.0f} TF/s | bf16 {t3*1e6:.0f} us {fl/t3/1e12:.0f} TF/s", flush=True)
+    print(f"conv{k} {H}x{W} {C}->{Co}: generic x3 {t*1e6:.0f} us {fl/t/1e12:.0f} TF/s | LDS-DMA records kernel {t4*1e6:.0f} us {fl/t4/1e12:.0f} TF/s | bf16 {t3*1e6:.0f} us {fl/t3/1e12:.0f} TF/s", flush=True)

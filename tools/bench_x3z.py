@@ -17,8 +17,7 @@ for kind in ("randn","zeros","randn","zeros"):
     w=torch.randn(Co,k*k*C,device=D)/math.sqrt(k*k*C) if kind=="randn" else torch.zeros(Co,k*k*C,device=D)
     ws=ops.split_records(w)
     hi=torch.empty(n*H*W,C,device=D,dtype=torch.bfloat16); lo=torch.empty_like(hi)
-    ts=timeit(lambda: ops.split_planes(x), iters=5)
-    for v in ("0","1"):
-        os.environ["SKIMI_X3_W4"]=v
+    ts=timeit(lambda: ops.split_records(x), iters=5)
+    for rep in range(2):
         t=timeit(lambda: ops.gemm(x,w,prec=PREC_BF16X3,conv=conv,out=o,w_split=ws,x3_scratch=sc),iters=5)
-        print(f"{kind} W4={v}: {t*1e6:.0f} us total, split pass ~{ts*1e6:.0f} us -> conv kernel ~{(t-ts)*1e6:.0f} us = {3*fl/(t-ts)/1e12:.0f} TF/s of MFMA work", flush=True)
+        print(f"{kind} run {rep}: {t*1e6:.0f} us total, split pass ~{ts*1e6:.0f} us -> conv kernel ~{(t-ts)*1e6:.0f} us = {3*fl/(t-ts)/1e12:.0f} TF/s of MFMA work", flush=True)

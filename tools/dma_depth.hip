@@ -158,6 +158,8 @@ void run(const unsigned short* A, const unsigned short* W, int M, int N, int K, 
     fflush(stdout);
 }
 
+// A is 43968 x 4096 and W 8192 x 8192 elements: run64 reads 2 * M * K (hi + lo) of A, run M * K; keep every
+// case inside those sizes (an out-of-range case faults the GPU)
 int main() {
     const int M = 8192, N = 8192, K = 8192;
     unsigned short *A, *W;
@@ -170,8 +172,6 @@ int main() {
     run64<2>(A, W, 8192, 2048, 2304, sink);
     run64<4>(A, W, 8192, 2048, 2304, sink);
     run64<6>(A, W, 8192, 2048, 2304, sink);
-    run64<4>(A, W, 65536, 256, 2304, sink);
-    run64<6>(A, W, 65536, 256, 2304, sink);
     run<1, 1, 8>(A, W, M, N, K, sink);
     run<2, 1, 8>(A, W, M, N, K, sink);
     run<3, 1, 8>(A, W, M, N, K, sink);
