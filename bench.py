@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="time steps of the clip per call (B)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent batches of --batch time steps per step, each issued from its own host thread on "
+                         "its own HIP stream (infer.process_multi_view_clip(streams=N)); 1 = one batch per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vp3d", action="store_true", help="skip the VideoPose3D lifter leg (profiling runs)")
     ap.add_argument("--cpu-views", type=int, default=2, help="views of the bounded CPU-baseline sample")
@@ -93,8 +96,52 @@ def main():
         out["joints3d"] = joints
         return out
 
+    # --streams N: N independent batches per step, one host thread + HIP stream each (what
+    # infer.process_multi_view_clip(streams=N) does with the calls of a clip)
+    NS = max(1, args.streams)
+    extra = [(torch.rand((B, S_VIEWS, 3, IMG, IMG), generator=g, device=dev, dtype=torch.float32),
+              torch.rand((B, S_VIEWS, 17, 2), generator=g, device=dev, dtype=torch.float32) * (IMG - 40) + 20)
+             for _ in range(NS - 1)]
+
+    def step_on(images_k, kps_k):
+        out = model(images_k, want=want)
+        E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (IMG, IMG))
+        out["joints3d"] = geometry.triangulate_joints(K, E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous(), kps_k)
+        return out
+
+    def step_multi(n_streams):
+        """one step = n_streams independent batches, each on its own stream from its own host thread: the
+        HBM-bound phases of one (GEMM store bursts, LayerNorm, upsamples) overlap the MFMA-bound phases of the
+        other.  The threads join before the step's one collective."""
+        import threading
+        from skiing_analysis_pytorch_amd.infer import _side_streams
+        main = torch.cuda.current_stream(dev)
+        side = _side_streams(dev, n_streams)   # long-lived: the model keeps one workspace per stream
+        outs = [None] * n_streams
+        batches = [(images, kps)] + extra
+
+        def worker(k):
+            with torch.cuda.device(dev), torch.cuda.stream(side[k]):
+                outs[k] = step_on(*batches[k])
+        for s_ in side:
+            s_.wait_stream(main)
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(n_streams)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        for s_ in side:
+            main.wait_stream(s_)
+        joints = torch.cat([o["joints3d"] for o in outs])
+        if use_dist:
+            joints = parallel.all_gather_steps(joints, world * n_streams * B)
+        out = outs[0]
+        out["joints3d"] = joints
+        return out
+
+    step()   # prepares the handle for this frame shape (and is the one-stream warm-up)
     for _ in range(args.warmup):
-        step()
+        step() if NS == 1 else step_multi(NS)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -105,7 +152,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = step() if NS == 1 else step_multi(NS)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -117,9 +164,9 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(out["pose_enc"]).all() and out["joints3d"].shape == (world * B, 17, 3)
+    assert torch.isfinite(out["pose_enc"]).all() and out["joints3d"].shape == (world * NS * B, 17, 3)
 
-    frames = world * args.steps * B
+    frames = world * args.steps * B * NS
     value = frames / elapsed
     line = {
         "metric": "3D-pose frames/sec, 8-view 518px clips",
@@ -136,10 +183,10 @@ def main():
         "data": "synthetic",
         "config": {"workload": "VGGT-1B multi_view_process step: 8 views x 518x518, camera+depth+point heads, "
                                "pose->cameras + 8-view DLT of 17 joints (+ all-gather of the joints across ranks)",
-                   "views": S_VIEWS, "image": IMG, "time_steps_per_call": B, "parallelism": f"clip-dp{world}",
+                   "views": S_VIEWS, "image": IMG, "time_steps_per_call": B, "streams": NS, "parallelism": f"clip-dp{world}",
                    "aggregator_prec": "bf16 MFMA, fp32 accumulate/residual/LayerNorm/softmax",
                    "head_prec": "bf16x3 (fp32-accurate)"},
-        "whole_path_tflops": vggt_flops_per_step(S_VIEWS) * B * args.steps * world / elapsed / 1e12,
+        "whole_path_tflops": vggt_flops_per_step(S_VIEWS) * B * NS * args.steps * world / elapsed / 1e12,
     }
     if n.value > 0:
         avg_s = ms.value * 1e-3 / n.value
@@ -150,6 +197,16 @@ def main():
                             "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(B),
                             "avg_launch_us": avg_s * 1e6, "launches": int(n.value),
                             "flops_per_launch": flops_per_launch}
+    if rank == 0 and world == 1 and NS > 1 and "roofline" in line:
+        # outside the timed region: the same kernel with the chip to itself (one batch, one stream)
+        _lib.check(lib.skimi_profile_start(1, seq_global), "profile_start")
+        step()
+        torch.cuda.synchronize()
+        _lib.check(lib.skimi_profile_stop(C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "profile_stop")
+        if n.value > 0:
+            a1 = fl.value / (ms.value * 1e-3) / 1e12
+            line["roofline"]["one_stream"] = {"achieved": a1, "frac": a1 / PEAK_BF16_TFLOPS,
+                                              "avg_launch_us": ms.value * 1e3 / n.value, "launches": int(n.value)}
     if rank == 0 and world == 1 and not args.no_vp3d:
         line["vp3d"] = vp3d_leg(dev, cpu=not args.no_cpu_baseline)
     if rank == 0 and cpu_sd is not None:

@@ -1,6 +1,7 @@
 // C-ABI surface of libskimi.so: error channel, version, generic ops.
 #include <stdarg.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -27,9 +28,14 @@ struct ProfState {
     hipEvent_t pending = nullptr;
 };
 static ProfState g_prof;
+// launches may come from several host threads (one per stream): the event list is shared, the
+// bracket of a launch is found again through the launching thread's own index
+static std::mutex g_prof_mu;
+static thread_local size_t tl_prof_idx = 0;
 
 bool prof_armed(int kind, long size_key) { return g_prof.kind == kind && size_key >= g_prof.min_key; }
 void prof_before(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     std::pair<hipEvent_t, hipEvent_t> e;
     if (!g_prof.pool.empty()) {
         e = g_prof.pool.back();
@@ -40,9 +46,12 @@ void prof_before(hipStream_t st) {
     }
     (void)hipEventRecord(e.first, st);
     g_prof.ev.push_back(e);
+    tl_prof_idx = g_prof.ev.size() - 1;
 }
 void prof_after(hipStream_t st, double flops, double bytes) {
-    (void)hipEventRecord(g_prof.ev.back().second, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (tl_prof_idx >= g_prof.ev.size()) return;   // profile_stop ran in between
+    (void)hipEventRecord(g_prof.ev[tl_prof_idx].second, st);
     g_prof.flops += flops;
     g_prof.bytes += bytes;
 }

@@ -76,7 +76,7 @@ class VGGT:
         self._h = lib().skimi_vggt_create(C.byref(cc))
         if not self._h:
             raise _lib.SkimiError(lib().skimi_last_error().decode())
-        self._ws = None
+        self._ws = {}   # (device, stream) -> workspace
         self.training = False
 
     def __del__(self):
@@ -191,11 +191,16 @@ class VGGT:
         need = lib().skimi_vggt_workspace_bytes(self._h, B, S, H, W, nq)
         if need == 0:
             raise _lib.SkimiError(lib().skimi_last_error().decode())
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        # one workspace per stream: forwards issued from different host threads on different streams
+        # (infer.process_multi_view_clip(streams=2)) run concurrently on the device; the handle itself is
+        # read-only once a frame shape has been prepared by a first call
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws.pop(key, None)
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
         check(lib().skimi_vggt_forward(self._h, ptr(images), ptr(query_points) if nq else None, B, S, H, W, nq,
-                                       C.byref(outs), ptr(self._ws), self._ws.numel(), _lib.current_stream()),
+                                       C.byref(outs), ptr(ws), ws.numel(), _lib.current_stream()),
               "skimi_vggt_forward")
         if not self.training:
             preds["images"] = images   # vggt.py:93-94
