@@ -27,14 +27,17 @@ for name, gx, wx, d in load_rows(trace):
 line = json.load(open(linef))
 out = []
 out.append("# Round 1 — rocprofv3 --kernel-trace --stats of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vp3d`\n")
-out.append(f"MI355X (gfx950); {NS} steps in the trace (1 warm-up + {NS-1} timed); one step = 4 time steps x 8 views x 518x518 (the default `--batch 4`).")
-out.append(f"Total kernel time {tot/1e6:.1f} ms = {tot/NS/1e6:.1f} ms per step (includes the one-off weight upload / synthetic-weight kernels of the first step).\n")
-out.append("| kernel | ms / step | % | calls / step | avg us |\n|---|---:|---:|---:|---:|")
+out.append(f"MI355X (gfx950); {NS} batch forwards in the trace (1 one-stream preparation, then 1 warm-up and 2 timed steps of 2 concurrent batches each, `--streams 2`); one batch = 4 time steps x 8 views x 518x518 (`--batch 4`).")
+out.append(f"Total kernel time {tot/1e6:.1f} ms = {tot/NS/1e6:.1f} ms per batch (summed kernel durations: with two batches in flight kernels of the two streams share the chip, so this is more than the wall time; includes the one-off weight upload / synthetic-weight kernels of the first forward).\n")
+out.append("| kernel | ms / batch | % | calls / batch | avg us |\n|---|---:|---:|---:|---:|")
 for n, v in sorted(byk.items(), key=lambda kv: -kv[1][0])[:24]:
     out.append(f"| `{n[:90]}` | {v[0]/NS/1e6:.2f} | {100*v[0]/tot:.1f} | {v[1]/NS:.0f} | {v[0]/v[1]/1e3:.1f} |")
 rf = line['roofline']
 out.append(f"\nUn-profiled bench line of the same build (`profiles/r01_bench_line.json`, full default run incl. the CPU legs):")
-out.append(f"- value {line['value']:.2f} frames/s, {line['ms_per_step']:.1f} ms/step (4 time steps), whole path {line['whole_path_tflops']:.0f} TFLOP/s")
+out.append(f"- value {line['value']:.2f} frames/s, {line['ms_per_step']:.1f} ms/step (one step = {line['config'].get('streams', 1)} concurrent batches of 4 time steps), whole path {line['whole_path_tflops']:.0f} TFLOP/s")
+one = rf.get('one_stream')
+if one:
+    out.append(f"- the same kernel with the chip to itself (one batch, one stream; measured by bench.py right after the timed region): {one['achieved']:.0f} TFLOP/s = {100*one['frac']:.1f}% (avg launch {one['avg_launch_us']:.0f} us over {one['launches']} launches)")
 out.append(f"- roofline: {rf['kernel']}: {rf['achieved']:.0f} TFLOP/s = {100*rf['frac']:.1f}% of {rf['peak']:.0f} (avg launch {rf['avg_launch_us']:.0f} us over {rf['launches']} launches, HIP events on the launch stream inside bench.py); HBM traffic {rf['traffic']/1e6:.0f} MB per launch (`profiles/r01_attn_traffic.json`: FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes) against {4*10992*1024*2*4/1e6:.0f} MB algorithmic (q, k, v read once, o written once).  Run-to-run: fresh boxes differ by several % (clocks, thermal state): 16.4-18.1 frames/s and 923-982 TFLOP/s were measured for this build.")
 cb = line['cpu_baseline']
 out.append(f"- cpu_baseline: {cb['value']:.4f} frames/s on {cb['cores']} cores ({cb['sample']})")
@@ -42,7 +45,7 @@ vp = line.get('vp3d')
 if vp:
     out.append(f"- vp3d leg: {vp['clips_1']['us_per_call']:.0f} us per 243-frame clip at B=1 ({vp['clips_1']['achieved_GBps']:.0f} GB/s on the algorithmic bytes), {vp['clips_64']['us_per_call']/64:.1f} us per clip at B=64; CPU oracle {vp['cpu_oracle']['s_per_clip_with_flip_tta']*1e3:.1f} ms per clip on {vp['cpu_oracle']['cores']} cores (see `profiles/r01_vp3d_summary.md`)")
 out.append("\nPer-shape split of the attention kernel from the same trace (grouped by grid size):\n")
-out.append("| launches / step | grid (threads) | shape | avg us |\n|---:|---:|---|---:|")
+out.append("| launches / batch | grid (threads) | shape | avg us |\n|---:|---:|---|---:|")
 ga = None
 for k, v in sorted(g.items(), key=lambda kv: -kv[1][0]):
     if 'attn' in k[0]:
