@@ -200,16 +200,22 @@ def process_multi_view_clip(model: VGGT, frames: torch.Tensor, keypoints: torch.
     want = {"camera", "depth", "point"} if want_dense else {"camera"}
     starts = list(range(lo, hi, steps_per_call))
 
+    n_par = max(1, min(int(streams), len(starts) - 1))
+
     def one_call(a):
         b = min(a + steps_per_call, hi)
         idx = [min(i, T - 1) for i in range(a, b)]          # padded steps repeat the last one
+        n = len(idx)
+        if n_par > 1:
+            # concurrent calls on one handle must all have one shape (the handle's per-shape tables are
+            # rebuilt when it changes): a short last chunk is filled up and cut again below
+            idx = idx + [idx[-1]] * (steps_per_call - n)
         out = model(frames[idx], want=want)
         E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (H, W))
         R, t = E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous()
-        return geometry.triangulate_joints(K, R, t, keypoints[idx]), E, K
+        return geometry.triangulate_joints(K, R, t, keypoints[idx])[:n], E[:n], K[:n]
 
     results = [None] * len(starts)
-    n_par = max(1, min(int(streams), len(starts) - 1))
     if n_par <= 1:
         for i, a in enumerate(starts):
             results[i] = one_call(a)
