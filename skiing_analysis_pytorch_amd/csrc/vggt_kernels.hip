@@ -201,15 +201,16 @@ __global__ __launch_bounds__(256) void bilinear_ac_planes_kernel(const float* __
             lo[k] = (short)f2bf(r[k] - bf2f(hb));
         }
         const long pix = ((n * H + Y) * (long)W + X) * 2 * C;
+        // written once, read back much later by the conv (gigabytes in between): streaming stores
         if (slice_records) {
             const int c = c8 * 8;
             const long o = pix + (c >> 5) * 64 + (c & 31);
-            *reinterpret_cast<bf16x8*>(out + o) = hi;
-            *reinterpret_cast<bf16x8*>(out + o + 32) = lo;
+            __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8*>(out + o));
+            __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8*>(out + o + 32));
         } else {
             const long o = pix + c8 * 8;
-            *reinterpret_cast<bf16x8*>(out + o) = hi;
-            *reinterpret_cast<bf16x8*>(out + o + C) = lo;
+            __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8*>(out + o));
+            __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8*>(out + o + C));
         }
     }
 }
