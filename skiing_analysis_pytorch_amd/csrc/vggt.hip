@@ -17,6 +17,8 @@
 
 #include <map>
 #include <string>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include <stdlib.h>
@@ -112,6 +114,8 @@ struct skimi_vggt {
     TrackW track;
     // per-resolution tables (prepare())
     int prepH = 0, prepW = 0, prepF = 0;
+    std::mutex prep_mu;             // guards prepare(); see skimi_vggt_forward
+    std::atomic<int> inflight{0};   // forward calls between their prepare() and their return
     int* pos = nullptr;             // int32 [F*P, 2]
     float *rope_cos = nullptr, *rope_sin = nullptr;
     int rope_npos = 0;
@@ -1090,7 +1094,24 @@ int skimi_vggt_forward(skimi_vggt* h, const float* images, const float* query_po
     }
     int rc;
     if ((rc = check_shape(h, B, S, H, W))) return rc;
-    if ((rc = prepare(h, B * S, S, H, W))) return rc;
+    // Calls of one shape may run at the same time from several host threads (own workspace and
+    // stream each).  A new shape rebuilds the handle's tables: refused while another call is still
+    // enqueueing (the hipFree inside prepare() waits for work already on the device).
+    struct InFlight {
+        skimi_vggt* h;
+        ~InFlight() { h->inflight.fetch_sub(1); }
+    };
+    {
+        std::lock_guard<std::mutex> lk(h->prep_mu);
+        const bool same = h->prepH == H && h->prepW == W && h->prepF == B * S;
+        if (!same && h->inflight.load() > 0) {
+            set_error("skimi_vggt_forward: a call with another frame shape is in flight on this handle");
+            return SKIMI_ERR_STATE;
+        }
+        if ((rc = prepare(h, B * S, S, H, W))) return rc;
+        h->inflight.fetch_add(1);
+    }
+    InFlight guard{h};
     Ctx c{h, (hipStream_t)stream};
     c.ar.base = (char*)workspace;
     c.ar.cap = workspace_bytes;
