@@ -14,6 +14,11 @@
 //     32-lane halves with one v_permlane32_swap instead of an LDS bpermute, row sums are plain
 //     per-lane partial sums merged once at the end (no ones-matrix MFMAs).
 // Workgroup: 4 waves x 64 queries; K/V tiles of 64 keys double-buffered in LDS by LDS-DMA.
+//
+// Tried on top of this, no gain (2327-2344 us against 2307-2311 for the bench's global-attention launch):
+// the two query blocks skewed, i.e. block 1's S^T MFMAs issued in one straight-line region with block 0's
+// softmax (last tile peeled) so that they run under its VALU stream.  The loop is VALU- and power-bound
+// (zero operands: 1144-1218 TFLOP/s, tools/mb_attn_power.py), not short of MFMA / VALU overlap.
 #include <stdlib.h>
 
 #include "common.h"
