@@ -205,3 +205,26 @@ def test_joint_and_prediction_writers(tmp_path):
     q = formats.save_predictions_npz(tmp_path / "out", preds)
     z = np.load(q)
     assert sorted(z.files) == ["depth", "pose_enc"] and z["depth"].shape == (1, 2, 4, 4, 1)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r01_bench_line.json is one line of bench.py's output: the driver's contract fields plus the
+    `roofline` and `cpu_baseline` objects, internally consistent."""
+    import json
+    from pathlib import Path
+
+    line = json.loads((Path(__file__).resolve().parent.parent / "profiles" / "r01_bench_line.json").read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["unit"] == "frames/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None and "workload" in line["config"] and "model" not in line["config"]
+    cfg = line["config"]
+    frames_per_step = cfg["time_steps_per_call"] * cfg.get("streams", 1) * line["n_gpus"]
+    assert abs(line["value"] - frames_per_step / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    rf = line["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert abs(rf["achieved"] - rf["flops_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e12) < 1e-6 * rf["achieved"]
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
