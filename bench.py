@@ -259,6 +259,32 @@ def vp3d_leg(dev, cpu=True):
         res[f"clips_{B}"] = {"us_per_call": t * 1e6, "clips_per_s": B / t, "frames_per_s": B * 243 / t,
                              "algorithmic_GB": (wbytes + act) / 1e9, "achieved_GBps": (wbytes + act) / t / 1e9,
                              "frac_of_hbm_peak": (wbytes + act) / t / 8e12}
+    # the receptive-field-243 lifter of BASELINE configs[4] (5 blocks, 67.8 MB of fp32 weights): 485 input
+    # frames -> 243 output frames
+    fw5 = [3, 3, 3, 3, 3]
+    sd5 = W.make_vp3d_state_dict(seed=0, filter_widths=fw5)
+    m5 = vp3d.TemporalModel(17, 2, 17, fw5, prec=PREC_BF16X3)
+    m5.load_state_dict(sd5)
+    wbytes5 = sum(v.numel() * 4 for k, v in sd5.items() if k.endswith("weight") and v.dim() == 3)
+    res["rf243"] = {"model": "TemporalModel RF 243 (filter widths 3,3,3,3,3), 1024 channels, bf16x3, 485 -> 243 frames"}
+    for B in (1, 64):
+        x = torch.randn(B, 485, 17, 2, device=dev)
+        out = torch.empty(B, 243, 17, 3, device=dev)
+        for _ in range(3):
+            m5(x, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 50 if B == 1 else 5
+        e0.record()
+        for _ in range(n):
+            m5(x, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / n
+        act = sum(2 * B * L * 1024 * 4 for L in (483, 477, 477, 459, 459, 405, 405, 243, 243)) * 2
+        res["rf243"][f"clips_{B}"] = {"us_per_call": t * 1e6, "clips_per_s": B / t, "frames_per_s": B * 243 / t,
+                                      "algorithmic_GB": (wbytes5 + act) / 1e9, "achieved_GBps": (wbytes5 + act) / t / 1e9,
+                                      "frac_of_hbm_peak": (wbytes5 + act) / t / 8e12}
+    del m5, sd5
     if cpu:
         from oracle import vp3d_oracle   # test infrastructure: the timed CPU baseline only
         kp = W.make_keypoints_2d(frames=243, seed=1).numpy()
