@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "kernels.h"
 
 using namespace skimi;
@@ -33,6 +34,7 @@ struct skimi_vp3d {
     void* w_expand = nullptr;
     float* b_expand = nullptr;
     std::vector<void*> w_conv;    // 2 per block
+    std::vector<void*> w_rec;     // fp32-accurate mode: the same matrices as bf16x3 records (LDS-DMA kernel, large batches)
     std::vector<float*> b_conv;
     void* w_shrink = nullptr;
     float* b_shrink = nullptr;
@@ -155,12 +157,28 @@ static int fold(skimi_vp3d* h, const std::string& conv, const std::string& bn, i
     return SKIMI_OK;
 }
 
+// fp32-accurate mode: a block's weight matrix [N, K] also as bf16x3 records, for the LDS-DMA kernel that
+// gemm_dispatch picks once a batch fills the chip with 256-row tiles (gemm_x3dma.hip)
+static int add_records(skimi_vp3d* h, const void* w_f32, int N, int K, bool bf16_mode) {
+    void* rec = nullptr;
+    if (!bf16_mode && K % 32 == 0) {
+        SKIMI_HIP(hipMalloc(&rec, (size_t)N * K * 4));
+        h->allocs.push_back(rec);
+        int rc = split_records_launch((const float*)w_f32, K, N, K, rec, nullptr);
+        if (rc) return rc;
+        SKIMI_HIP(hipStreamSynchronize(nullptr));
+    }
+    h->w_rec.push_back(rec);
+    return SKIMI_OK;
+}
+
 int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
     SKIMI_CHECK_ARG(h, "skimi_vp3d_finalize: null handle");
     SKIMI_CHECK_ARG(prec == SKIMI_PREC_BF16 || prec == SKIMI_PREC_BF16X3, "skimi_vp3d_finalize: bad prec");
     for (void* p : h->allocs) (void)hipFree(p);
     h->allocs.clear();
     h->w_conv.clear();
+    h->w_rec.clear();
     h->b_conv.clear();
     h->prec = prec;
     const bool bf = prec == SKIMI_PREC_BF16;
@@ -182,6 +200,7 @@ int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
         if ((rc = upload(h, b, false, (void**)&db))) return rc;
         h->w_conv.push_back(dw);
         h->b_conv.push_back(db);
+        if ((rc = add_records(h, dw, C, h->fw[i] * C, bf))) return rc;
         snprintf(cn, sizeof cn, "layers_conv.%zu", 2 * (i - 1) + 1);
         snprintf(bn, sizeof bn, "layers_bn.%zu", 2 * (i - 1) + 1);
         if ((rc = fold(h, cn, bn, C, C, 1, C, &w, &b))) return rc;
@@ -189,6 +208,7 @@ int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
         if ((rc = upload(h, b, false, (void**)&db))) return rc;
         h->w_conv.push_back(dw);
         h->b_conv.push_back(db);
+        if ((rc = add_records(h, dw, C, C, bf))) return rc;
     }
     const std::vector<float>*sw, *sb;
     const int nout = h->joints_out * 3;
@@ -201,12 +221,13 @@ int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
 }
 
 // workspace = A0 [B*L0, k0pad] + three activation buffers [B*L0, C] + split-K slab [B*L0, C]
+//           + scratch for the activation records of the LDS-DMA bf16x3 kernel [B*L0, C] + 256
 size_t skimi_vp3d_workspace_bytes(const skimi_vp3d* h, int32_t batch, int32_t frames_in) {
     if (!h || batch <= 0 || frames_in < skimi_vp3d_receptive_field(h)) return 0;
     const size_t L0 = (size_t)frames_in - h->fw[0] + 1;
     const size_t rows = (size_t)batch * L0;
     const size_t k0 = align_up((size_t)h->fw[0] * h->joints_in * h->in_features, 8);
-    return align_up(rows * k0 * 4, 256) + 4 * align_up(rows * h->channels * 4, 256);
+    return align_up(rows * k0 * 4, 256) + 4 * align_up(rows * h->channels * 4, 256) + align_up(rows * h->channels * 4 + 256, 256);
 }
 
 int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch, int32_t frames_in,
@@ -235,6 +256,8 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
     float* bufY = (float*)(ws + actb);
     float* bufZ = (float*)(ws + 2 * actb);
     void* slab = ws + 3 * actb;
+    void* x3s = ws + 4 * actb;
+    const size_t x3s_bytes = align_up(rows0 * C * 4 + 256, 256);
     const int wdt = h->prec == SKIMI_PREC_BF16 ? SKIMI_BF16 : SKIMI_F32;
 
     int rc;
@@ -272,6 +295,8 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
         d.M = batch * Lo; d.N = C; d.K = k * C;
         d.A = bufX; d.lda = C;
         d.W = h->w_conv[2 * (i - 1)]; d.ldw = (int64_t)k * C;
+        d.W_split = h->w_rec[2 * (i - 1)];   // qualifies (gemm_x3dma_eligible) from a few dozen clips per call on
+        d.x3_scratch = x3s; d.x3_scratch_bytes = x3s_bytes;
         d.bias = h->b_conv[2 * (i - 1)];
         d.resid = nullptr;
         d.out = bufY; d.ldo = C;
@@ -281,6 +306,7 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
         d.K = C;
         d.A = bufY; d.lda = C;
         d.W = h->w_conv[2 * (i - 1) + 1]; d.ldw = C;
+        d.W_split = h->w_rec[2 * (i - 1) + 1];
         d.bias = h->b_conv[2 * (i - 1) + 1];
         d.resid = bufX; d.ldr = C;
         d.resid_rows_per_batch = Lo;
@@ -300,6 +326,7 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
         L = Lo;
     }
     // shrink: 1x1 conv with bias, no activation
+    d.W_split = nullptr; d.x3_scratch = nullptr; d.x3_scratch_bytes = 0;
     d.a_mode = 0;
     d.act = SKIMI_ACT_NONE;
     d.M = batch * L; d.N = h->joints_out * 3; d.K = C;

@@ -63,6 +63,23 @@ def test_vp3d_bf16_mode_tolerance():
     assert rel < 3e-2, rel
 
 
+@pytest.mark.parametrize("fw,causal", [([3, 3, 3], False), ([3, 3, 3, 3, 3], False), ([3, 3, 3], True)])
+def test_vp3d_large_batch_takes_the_lds_dma_kernels(fw, causal):
+    """From a few dozen clips per call the block convolutions run on the LDS-DMA bf16x3 kernels (dilated 1-D
+    gather, tap-major K, row-remapped residual in the 1x1): every clip of a 64-clip batch equals its
+    single-clip result."""
+    m = _model(fw, causal, PREC_BF16X3)
+    rf = m.receptive_field()
+    frames = rf + 216
+    x = torch.randn(64, frames, 17, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    big = m(x)
+    assert big.shape == (64, frames - rf + 1, 17, 3)
+    for i in (0, 17, 63):
+        one = m(x[i:i + 1].contiguous())
+        # different accumulation orders (LDS-DMA kernel vs split-K atomics) on outputs of magnitude ~20
+        assert (big[i] - one[0]).abs().max().item() < 5e-5 * one[0].abs().max().item()
+
+
 def test_vp3d_out_buffer_reuse():
     """`out=` (beyond the reference signature) writes into a caller buffer; shape errors are loud."""
     fw = [3, 3, 3]
