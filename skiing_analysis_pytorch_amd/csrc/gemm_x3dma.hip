@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4_kernel(const GemmArgs p, con
                          (p.post_act == SKIMI_ACT_NONE || p.post_act == SKIMI_ACT_RELU);
     const bool fast = p.vec4 && p.store_mode == 0 && p.out_rpb == 0 && p.out_off == 0 && p.out2 == nullptr &&
                       p.out_dtype == SKIMI_F32 && p.gamma == nullptr && relu_ok && (p.resid != nullptr || p.resid2 == nullptr) &&
-                      (p.resid == nullptr || (p.resid_dtype == SKIMI_F32 && p.resid_rpb == 0 && p.resid_off == 0)) &&
+                      (p.resid == nullptr || p.resid_dtype == SKIMI_F32) &&
                       m0 + BM <= p.M && n0 + BN <= p.N;   // block-uniform
     if (fast) {
         const float lo1 = p.act == SKIMI_ACT_RELU ? 0.f : -__builtin_inff();
@@ -362,6 +362,12 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4_kernel(const GemmArgs p, con
         const float* rs = reinterpret_cast<const float*>(p.resid);
         const float* rs2 = reinterpret_cast<const float*>(p.resid2);
         float* out = reinterpret_cast<float*>(p.out);
+        // residual row of output row m (row_map's remap, branch-free: rows_per_batch 0 = one batch of all rows)
+        const int rpb = p.resid_rpb > 0 ? p.resid_rpb : 0x7fffffff;
+        auto res_row = [&](long m) {
+            const int b = (int)m / rpb;
+            return ((long)b * p.resid_bs + ((int)m - b * rpb) + p.resid_off) * p.ldr;
+        };
 #define SKIMI_X3_EPI_PASS(HAS_RES, HAS_OUT, HAS_REC)                                                                                 \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r)               \
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4_kernel(const GemmArgs p, con
             _Pragma("unroll") for (int it = 0; it < 8; ++it)                                                       \
                 v[it] = *reinterpret_cast<const float4*>(&stg[(half * 16 + it * 2 + lh) * 128 + 4 * (lane & 31)]); \
             if (HAS_RES) _Pragma("unroll") for (int it = 0; it < 8; ++it)                                          \
-                rr[it] = *reinterpret_cast<const float4*>(rs + (mrow + it * 2) * p.ldr + n);                       \
+                rr[it] = *reinterpret_cast<const float4*>(rs + res_row(mrow + it * 2) + n);                       \
             if (HAS_RES == 2) _Pragma("unroll") for (int it = 0; it < 8; ++it)                                     \
                 r2[it] = *reinterpret_cast<const float4*>(rs2 + (mrow + it * 2) * p.ldr2 + n);                     \
             _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                     \
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4n_kernel(const GemmArgs p, co
                          (p.post_act == SKIMI_ACT_NONE || p.post_act == SKIMI_ACT_RELU);
     const bool fast = p.vec4 && p.store_mode == 0 && p.out_rpb == 0 && p.out_off == 0 && p.out2 == nullptr &&
                       p.out_dtype == SKIMI_F32 && p.gamma == nullptr && relu_ok && (p.resid != nullptr || p.resid2 == nullptr) &&
-                      (p.resid == nullptr || (p.resid_dtype == SKIMI_F32 && p.resid_rpb == 0 && p.resid_off == 0)) &&
+                      (p.resid == nullptr || p.resid_dtype == SKIMI_F32) &&
                       m0 + BM <= p.M && n0 + BN <= p.N;   // block-uniform
     if (fast) {
         const float lo1 = p.act == SKIMI_ACT_RELU ? 0.f : -__builtin_inff();
@@ -649,6 +655,12 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4n_kernel(const GemmArgs p, co
         const float* rs = reinterpret_cast<const float*>(p.resid);
         const float* rs2 = reinterpret_cast<const float*>(p.resid2);
         float* out = reinterpret_cast<float*>(p.out);
+        // residual row of output row m (row_map's remap, branch-free: rows_per_batch 0 = one batch of all rows)
+        const int rpb = p.resid_rpb > 0 ? p.resid_rpb : 0x7fffffff;
+        auto res_row = [&](long m) {
+            const int b = (int)m / rpb;
+            return ((long)b * p.resid_bs + ((int)m - b * rpb) + p.resid_off) * p.ldr;
+        };
 #define SKIMI_X3N_EPI_PASS(HAS_RES, HAS_OUT, HAS_REC)                                                                                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r)               \
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4n_kernel(const GemmArgs p, co
         _Pragma("unroll") for (int it = 0; it < 8; ++it)                                                           \
             v[it] = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + 4 * (lane & 15)]);         \
         if (HAS_RES) _Pragma("unroll") for (int it = 0; it < 8; ++it)                                              \
-            rr[it] = *reinterpret_cast<const float4*>(rs + (mrow + it * 4) * p.ldr + n);                           \
+            rr[it] = *reinterpret_cast<const float4*>(rs + res_row(mrow + it * 4) + n);                           \
         if (HAS_RES == 2) _Pragma("unroll") for (int it = 0; it < 8; ++it)                                         \
             r2[it] = *reinterpret_cast<const float4*>(rs2 + (mrow + it * 4) * p.ldr2 + n);                         \
         _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                         \

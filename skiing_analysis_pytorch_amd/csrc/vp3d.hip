@@ -221,13 +221,13 @@ int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
 }
 
 // workspace = A0 [B*L0, k0pad] + three activation buffers [B*L0, C] + split-K slab [B*L0, C]
-//           + scratch for the activation records of the LDS-DMA bf16x3 kernel [B*L0, C] + 256
+//           + two buffers of bf16x3 activation records for the LDS-DMA kernel ([B*L0, C] + 256 each)
 size_t skimi_vp3d_workspace_bytes(const skimi_vp3d* h, int32_t batch, int32_t frames_in) {
     if (!h || batch <= 0 || frames_in < skimi_vp3d_receptive_field(h)) return 0;
     const size_t L0 = (size_t)frames_in - h->fw[0] + 1;
     const size_t rows = (size_t)batch * L0;
     const size_t k0 = align_up((size_t)h->fw[0] * h->joints_in * h->in_features, 8);
-    return align_up(rows * k0 * 4, 256) + 4 * align_up(rows * h->channels * 4, 256) + align_up(rows * h->channels * 4 + 256, 256);
+    return align_up(rows * k0 * 4, 256) + 4 * align_up(rows * h->channels * 4, 256) + 2 * align_up(rows * h->channels * 4 + 256, 256);
 }
 
 int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch, int32_t frames_in,
@@ -256,8 +256,9 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
     float* bufY = (float*)(ws + actb);
     float* bufZ = (float*)(ws + 2 * actb);
     void* slab = ws + 3 * actb;
-    void* x3s = ws + 4 * actb;
-    const size_t x3s_bytes = align_up(rows0 * C * 4 + 256, 256);
+    const size_t recb = align_up(rows0 * C * 4 + 256, 256);
+    char* recX = ws + 4 * actb;     // records of bufX (block input), or split scratch when the chain is off
+    char* recY = recX + recb;       // records of the dilated conv's output
     const int wdt = h->prec == SKIMI_PREC_BF16 ? SKIMI_BF16 : SKIMI_F32;
 
     int rc;
@@ -275,13 +276,39 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
     SKIMI_HIP(hipMemsetAsync(slab, 0, actb, st));
     d.act = SKIMI_ACT_RELU;
 
+    // Large batches (fp32-accurate mode): when every block GEMM qualifies for the LDS-DMA bf16x3 kernel with
+    // records as its A operand, activations travel from layer to layer as records written by the producing
+    // epilogue (no split pass; the dilated conv's output exists as records only).
+    bool chain = h->prec == SKIMI_PREC_BF16X3 && !h->w_rec.empty() && h->w_rec[0] != nullptr;
+    if (chain) {
+        int Lc = L0;
+        for (size_t i = 1; i < h->fw.size() && chain; ++i) {
+            const int k = h->fw[i], dil = h->dilation[i];
+            const int Lo = Lc - (k - 1) * dil;
+            skimi_gemm_desc q = d;
+            char* fake = (char*)(uintptr_t)0x10000000;
+            q.a_dtype = SKIMI_BF16X3_REC; q.A = fake; q.lda = C; q.W = fake; q.out = fake;
+            q.a_mode = 1; q.cN = batch; q.cH = 1; q.cW = Lc; q.cC = C; q.KH = 1; q.KW = k;
+            q.stride = 1; q.pad = 0; q.dil = dil; q.OH = 1; q.OW = Lo;
+            q.M = batch * Lo; q.N = C; q.K = k * C; q.W_split = h->w_rec[2 * (i - 1)];
+            q.x3_scratch = fake + (size_t)batch * Lc * C * 4; q.x3_scratch_bytes = 256;
+            chain = chain && Lo > 0 && gemm_x3dma_eligible(&q);
+            q.a_mode = 0; q.K = C; q.W_split = h->w_rec[2 * (i - 1) + 1];
+            q.x3_scratch = fake + (size_t)batch * Lo * C * 4;
+            chain = chain && gemm_x3dma_eligible(&q);
+            Lc = Lo;
+        }
+    }
+
     // expand: [B*L0, k0pad] x [C, k0pad]^T
     d.M = (int)rows0; d.N = C; d.K = h->k0pad;
     d.A = a0; d.lda = h->k0pad;
     d.W = h->w_expand; d.ldw = h->k0pad;
     d.bias = h->b_expand;
     d.out = bufX; d.ldo = C;
+    d.out_records = chain ? recX : nullptr;
     if ((rc = gemm_dispatch(&d, st, d.splitk_scratch, d.splitk_scratch_bytes, 0))) return rc;
+    d.out_records = nullptr;
 
     int L = L0;   // frames held by bufX, per batch element
     for (size_t i = 1; i < h->fw.size(); ++i) {
@@ -293,18 +320,33 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
         d.cN = batch; d.cH = 1; d.cW = L; d.cC = C; d.KH = 1; d.KW = k;
         d.stride = 1; d.pad = 0; d.dil = dil; d.OH = 1; d.OW = Lo;
         d.M = batch * Lo; d.N = C; d.K = k * C;
-        d.A = bufX; d.lda = C;
+        d.lda = C;
         d.W = h->w_conv[2 * (i - 1)]; d.ldw = (int64_t)k * C;
         d.W_split = h->w_rec[2 * (i - 1)];   // qualifies (gemm_x3dma_eligible) from a few dozen clips per call on
-        d.x3_scratch = x3s; d.x3_scratch_bytes = x3s_bytes;
         d.bias = h->b_conv[2 * (i - 1)];
         d.resid = nullptr;
-        d.out = bufY; d.ldo = C;
+        d.ldo = C;
+        if (chain) {
+            d.A = recX; d.a_dtype = SKIMI_BF16X3_REC;
+            d.x3_scratch = recX + (size_t)batch * L * C * 4; d.x3_scratch_bytes = 256;
+            d.out = nullptr; d.out_records = recY;
+        } else {
+            d.A = bufX; d.a_dtype = SKIMI_F32;
+            d.x3_scratch = recX; d.x3_scratch_bytes = recb;
+            d.out = bufY; d.out_records = nullptr;
+        }
         if ((rc = gemm_dispatch(&d, st, d.splitk_scratch, d.splitk_scratch_bytes, 0))) return rc;
         // conv 1x1 + BN + ReLU, then + res = x[:, pad+shift : L-pad+shift]  (model.py:129-135)
         d.a_mode = 0;
         d.K = C;
-        d.A = bufY; d.lda = C;
+        d.lda = C;
+        if (chain) {
+            d.A = recY;
+            d.x3_scratch = recY + (size_t)batch * Lo * C * 4;
+            d.out_records = recX;   // the block's output: fp32 (residual of the next block, shrink) and records
+        } else {
+            d.A = bufY;
+        }
         d.W = h->w_conv[2 * (i - 1) + 1]; d.ldw = C;
         d.W_split = h->w_rec[2 * (i - 1) + 1];
         d.bias = h->b_conv[2 * (i - 1) + 1];
@@ -327,6 +369,7 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
     }
     // shrink: 1x1 conv with bias, no activation
     d.W_split = nullptr; d.x3_scratch = nullptr; d.x3_scratch_bytes = 0;
+    d.a_dtype = SKIMI_F32; d.out_records = nullptr;
     d.a_mode = 0;
     d.act = SKIMI_ACT_NONE;
     d.M = batch * L; d.N = h->joints_out * 3; d.K = C;
