@@ -406,11 +406,6 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
                         "skimi_gemm: out_records needs N %% 32 == 0, plain output rows, no out2, 128-byte alignment");
         SKIMI_CHECK_ARG(d->out || d->out_dtype == SKIMI_F32, "skimi_gemm: records-only output is written from fp32 results");
         SKIMI_CHECK_ARG(d->prec == SKIMI_PREC_BF16X3, "skimi_gemm: out_records is an output form of the fp32-accurate mode");
-        // the zero page behind the records (padding taps of the consumer's gather)
-        if (hipMemsetAsync((char*)d->out_records + (size_t)d->M * (d->N / 32) * 128, 0, 256, st) != hipSuccess) {
-            set_error("hipMemsetAsync(out_records zero page) failed");
-            return SKIMI_ERR_HIP;
-        }
     }
     SKIMI_CHECK_ARG(d->lda % 4 == 0 && d->ldw % 8 == 0 && d->lda >= 0,
                     "skimi_gemm: lda/ldw must keep 16-B alignment (lda=%ld ldw=%ld)", (long)d->lda, (long)d->ldw);
@@ -466,6 +461,13 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
         a.partial = nullptr;
         a.k_per_split = d->K;
         return gemm_x3dma_launch(a, d, st);
+    }
+    // the zero page behind the records (padding taps of the consumer's gather): the LDS-DMA kernels above
+    // clear it themselves, the generic kernels get a memset node
+    if (d->out_records &&
+        hipMemsetAsync((char*)d->out_records + (size_t)d->M * (d->N / 32) * 128, 0, 256, st) != hipSuccess) {
+        set_error("hipMemsetAsync(out_records zero page) failed");
+        return SKIMI_ERR_HIP;
     }
     SKIMI_CHECK_ARG(d->a_dtype != SKIMI_BF16X3_REC,
                     "skimi_gemm: A given as bf16x3 records, but the launch does not qualify for the LDS-DMA kernel "

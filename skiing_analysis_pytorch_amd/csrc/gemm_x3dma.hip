@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4_kernel(const GemmArgs p, con
     const int tm = id / p.ntn, tn = id - tm * p.ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = (p.K + BK - 1) / BK;
+    // records output: the 256 zero bytes behind them (the consumer's padding taps)
+    if (p.out_rec != nullptr && blockIdx.x == 0 && tid < 16)
+        reinterpret_cast<uint4*>(p.out_rec + (long)p.M * p.rec_row)[tid] = uint4{0, 0, 0, 0};
 
     // ---- staging: a piece is 16 wave-instructions of 8 rows x 128 B; this wave issues 4*wave + j ----
     unsigned a_off[2][4], w_off[2][4];
@@ -466,6 +469,9 @@ __global__ __launch_bounds__(256, 1) void gemm_x3w4n_kernel(const GemmArgs p, co
     const int tm = id / p.ntn, tn = id - tm * p.ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = (p.K + BK - 1) / BK;
+    // records output: the 256 zero bytes behind them (the consumer's padding taps)
+    if (p.out_rec != nullptr && blockIdx.x == 0 && tid < 16)
+        reinterpret_cast<uint4*>(p.out_rec + (long)p.M * p.rec_row)[tid] = uint4{0, 0, 0, 0};
 
     // ---- staging (see gemm_x3w4_kernel): a piece is 16 wave-instructions of 8 rows x 128 B ----
     unsigned a_off[2][4], w_off[4];
