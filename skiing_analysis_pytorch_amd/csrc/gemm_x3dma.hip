@@ -774,7 +774,7 @@ bool gemm_x3dma_eligible(const skimi_gemm_desc* d) {
     static long min_tiles = -1;
     if (min_tiles < 0 || dyn) min_tiles = getenv("SKIMI_X3_MIN_TILES") ? atol(getenv("SKIMI_X3_MIN_TILES")) : 160;
     const long tiles = cdiv(d->M, 256) * (d->N > 128 ? cdiv(d->N, 256) : 1);
-    return d->M >= 4096 && d->N >= 96 && tiles >= min_tiles;
+    return d->M >= (min_tiles <= 1 ? 256 : 4096) && d->N >= 96 && tiles >= min_tiles;
 }
 
 template <int AMODE, int ABL = 0>

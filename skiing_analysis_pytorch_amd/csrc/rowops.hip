@@ -106,12 +106,27 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         }
         if (out_dtype == SKIMI_F32) {
             *reinterpret_cast<float4*>((float*)out + orow * ldo + c) = make_float4(y[0], y[1], y[2], y[3]);
+        } else if (out_dtype == SKIMI_BF16X3_REC) {
+            // bf16x3 records [rows][C/32][hi 32 | lo 32] (the A operand of the LDS-DMA bf16x3 GEMM; ldo unused)
+            bf16x4 h, l;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned short hb = f2bf(y[k]);
+                h[k] = (short)hb;
+                l[k] = (short)f2bf(y[k] - bf2f(hb));
+            }
+            unsigned short* q = (unsigned short*)out + orow * (2L * C) + (c >> 5) * 64 + (c & 31);
+            *reinterpret_cast<bf16x4*>(q) = h;
+            *reinterpret_cast<bf16x4*>(q + 32) = l;
         } else {
             bf16x4 h;
             h[0] = (short)f2bf(y[0]); h[1] = (short)f2bf(y[1]); h[2] = (short)f2bf(y[2]); h[3] = (short)f2bf(y[3]);
             *reinterpret_cast<bf16x4*>((unsigned short*)out + orow * ldo + c) = h;
         }
     }
+    // records: the 256 zero bytes behind them
+    if (out_dtype == SKIMI_BF16X3_REC && blockIdx.x == 0 && threadIdx.x < 16)
+        reinterpret_cast<uint4*>((unsigned short*)out + rows * (2L * C))[threadIdx.x] = uint4{0, 0, 0, 0};
 }
 
 int layernorm_launch(const float* x, const float* x2, int64_t ldx, int64_t rows, int C, const float* gamma,
@@ -121,11 +136,14 @@ int layernorm_launch(const float* x, const float* x2, int64_t ldx, int64_t rows,
     SKIMI_CHECK_ARG(C <= 64 * 32, "skimi_layernorm: C=%d exceeds 2048", C);
     SKIMI_CHECK_ARG(x2 == nullptr || (C % 2 == 0), "skimi_layernorm: concat needs even C");
     dim3 grid((unsigned)cdiv(rows, 4)), block(256);
+    SKIMI_CHECK_ARG(out_dtype != SKIMI_BF16X3_REC || (C % 256 == 0 && ((uintptr_t)out & 127) == 0),
+                    "skimi_layernorm: records output needs C %% 256 == 0 and a 128-byte aligned buffer");
     {
         auto al16 = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
         const bool vec = C % 256 == 0 && (x2 == nullptr || (C / 2) % 256 == 0) && ldx % 4 == 0 && ldo % 4 == 0 &&
                          al16(x) && al16(x2) && al16(gamma) && al16(beta) &&
                          ((uintptr_t)out & (out_dtype == SKIMI_F32 ? 15 : 7)) == 0;
+        SKIMI_CHECK_ARG(out_dtype != SKIMI_BF16X3_REC || vec, "skimi_layernorm: records output needs 16-byte aligned, 4-element strided operands");
         if (vec) {
 #define LNV_GO(V) hipLaunchKernelGGL(layernorm_vec_kernel<V>, grid, block, 0, st, x, x2, (long)ldx, (long)rows, gamma, beta, eps, out, out_dtype, (long)ldo, (long)grp_rows, (long)grp_stride, (long)grp_off)
             switch (C / 256) {

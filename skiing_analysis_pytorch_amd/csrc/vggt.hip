@@ -360,7 +360,7 @@ struct Ctx {
         d.W = L.w; d.w_dtype = L.wdt; d.ldw = L.K;
         d.prec = L.prec;
         d.splitk_scratch_zeroed = 1;
-        d.W_split = M >= 4096 ? L.w_split : nullptr;
+        d.W_split = L.w_split;   // gemm_x3dma_eligible decides (shape, tile count)
         d.bias = L.b;
         d.out = out; d.out_dtype = out_dt; d.ldo = ldo;
         return d;
@@ -465,12 +465,24 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
     {
         const size_t mk2 = c.ar.mark();
         void* lnb = c.ar.alloc((size_t)F * np * D * es);
+        void* lnb_rec = adt == SKIMI_F32 ? c.ar.alloc((size_t)F * np * D * 4 + 256) : nullptr;   // LayerNorm output as bf16x3 records
         for (int i = 0; i < 4; ++i) {
             const size_t mk3 = c.ar.mark();
-            c.ln(sf[i], sg[i], C, (long)F * np, D, w.norm, 1e-5f, lnb, adt, np, P, nsp);
             void* t0 = c.ar.alloc((size_t)F * np * w.oc[i] * es);
             {
+                // wide projections run on the LDS-DMA bf16x3 kernel: the LayerNorm writes their operand records
                 auto d = c.desc(w.proj[i], lnb, adt, D, F * np, t0, adt, w.oc[i]);
+                bool rec_in = false;
+                if (adt == SKIMI_F32 && D % 256 == 0 && w.proj[i].w_split != nullptr) {
+                    auto q = d;
+                    q.a_dtype = SKIMI_BF16X3_REC;
+                    q.x3_scratch = (char*)lnb_rec + (size_t)F * np * D * 4;
+                    q.x3_scratch_bytes = 256;
+                    q.A = lnb_rec;
+                    rec_in = gemm_x3dma_eligible(&q);
+                    if (rec_in) d = q;
+                }
+                c.ln(sf[i], sg[i], C, (long)F * np, D, w.norm, 1e-5f, rec_in ? lnb_rec : lnb, rec_in ? SKIMI_BF16X3_REC : adt, np, P, nsp);
                 c.gemm(d);
             }
             if (w.pos_embed && !c.rc && !c.dry()) {
