@@ -40,7 +40,6 @@ CXXFLAGS = [
 EXTRA_FLAGS = {
     "attention_bf16.hip": ["-fno-slp-vectorize"],
     "attention_q64.hip": ["-fno-slp-vectorize"],
-    "attention_pipe.hip": ["-fno-slp-vectorize"],
 }
 
 

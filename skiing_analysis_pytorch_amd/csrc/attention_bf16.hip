@@ -233,12 +233,9 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
     const bool prof = prof_armed(PROF_ATTN_BF16, a.seq_k);
     if (prof) prof_before(st);
     static const int dbg = getenv("SKIMI_ATTN_ABL") ? atoi(getenv("SKIMI_ATTN_ABL")) : 0;
-    // SKIMI_ATTN_Q64: 1 (default) the 64-query-per-wave kernel; 0 this file's 32-query kernel;
-    // 2 the skewed half-step pipeline of attention_pipe.hip (experiment, ~4 % slower: see its header)
+    // SKIMI_ATTN_Q64: 1 (default) the 64-query-per-wave kernel; 0 this file's 32-query kernel
     static const int q64 = getenv("SKIMI_ATTN_Q64") ? atoi(getenv("SKIMI_ATTN_Q64")) : 1;
-    if (q64 == 2) {
-        attention_pipe_dispatch(a, st);
-    } else if (q64 == 1) {
+    if (q64 != 0) {
         attention_q64_dispatch(a, st);
     } else
     switch (dbg) {

@@ -42,7 +42,6 @@ int conv_direct_n32_launch(const unsigned short* in_hi, const unsigned short* in
                            const float* bias, float* out, int F, int H, int W, int C, int relu, hipStream_t st,
                            long px_stride = 0);   // 0: separate planes [.., C]; 2C: pixel records [hi C | lo C]
 void attention_q64_dispatch(const AttnArgs& a, hipStream_t st);    // attention_q64.hip: 64 queries per wave
-void attention_pipe_dispatch(const AttnArgs& a, hipStream_t st);   // attention_pipe.hip: skewed half-step pipeline
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
                      hipStream_t st);
 

@@ -239,11 +239,10 @@ def test_attention_bf16(batch, seq, heads):
     assert err < 2e-2, err
 
 
-@pytest.mark.parametrize("variant", ["0", "2"])
+@pytest.mark.parametrize("variant", ["0"])
 def test_attention_bf16_other_kernels(variant):
-    """The default is the 64-query kernel; SKIMI_ATTN_Q64=0 (32-query kernel) and =2 (skewed half-step
-    pipeline) stay selectable for A/B timing and must stay correct.  The switch is read once per
-    process, so each variant runs in a child process."""
+    """The default is the 64-query kernel; SKIMI_ATTN_Q64=0 (the first, 32-query kernel) stays selectable for
+    A/B timing and must stay correct.  The switch is read once per process, so it runs in a child process."""
     import os, subprocess, sys
     code = (
         "import torch, torch.nn.functional as F\n"
