@@ -49,6 +49,6 @@ for B, f in ((1, fwd[4]), (64, fwd[-1])):
             md.append(f"| {nm} | `{n}` | {us:.1f} | {mb:.1f} | {mb / us * 1e3:.0f} | {fl / us / 1e6:.1f} |")
         else: md.append(f"| | `{n}` | {us:.1f} | | | |")
     md.append("")
-md.append("At B = 1 the dilated convolutions read their 12.6 MB of fp32 weights in 19-20 us (0.74-0.76 TB/s, split-K over the CUs); the forward is a chain of 13 short dependent kernels of 4-20 us each (the split-K reduce launches alone are 24 us, the memset and im2col 7 us), about 98 us per call un-profiled (bench.py `vp3d.clips_1`).  A hipGraph replay of the chain was measured no faster (104 vs 96 us): the cost is kernel time, not launch overhead.  Folding the reduce into the last-arriving workgroup would trade each 5-us reduce launch for an agent-scope release fence per workgroup (about 2 us, MI355X_MICROARCH.md) plus the last workgroup's pass: not pursued.  From a few dozen clips per call the block convolutions run on the LDS-DMA bf16x3 kernels (`gemm_x3w4_kernel`, 3 MFMAs per product, MFMA-bound): 15 us per clip at B = 64.")
+md.append("At B = 1 the dilated convolutions read their 12.6 MB of fp32 weights in 19-20 us (0.74-0.76 TB/s, split-K over the CUs); the forward is a chain of 13 short dependent kernels of 4-20 us each (the split-K reduce launches alone are 24 us, the memset and im2col 7 us), about 98 us per call un-profiled (bench.py `vp3d.clips_1`).  A hipGraph replay of the chain was measured no faster (104 vs 96 us): the cost is kernel time, not launch overhead.  Folding the reduce into the last-arriving workgroup would trade each 5-us reduce launch for an agent-scope release fence per workgroup (about 2 us, MI355X_MICROARCH.md) plus the last workgroup's pass: not pursued.  HBM traffic of the same forward by PMC (`profiles/r01_vp3d_pmc_hbm.csv`, separate FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 for 16-byte-per-lane loads on gfx950): 15.3 MB fetched by a dilated-conv launch against 14.5 MB of operands, 5.2 MB by a 1x1 launch against 5.1 MB, since each XCD owns whole K ranges of a split-K launch (51 MB and 18 MB before: every XCD holding a tile of a column pulled that column's weights through its own L2); the launch times did not move (19.6 us), i.e. the B = 1 chain is bound by the dependent load -> MFMA -> atomic round trips of its short K loops, not by bytes.  From a few dozen clips per call the block convolutions run on the LDS-DMA bf16x3 kernels (`gemm_x3w4_kernel`, 3 MFMAs per product, MFMA-bound): 15 us per clip at B = 64.")
 open(outp, 'w').write("\n".join(md) + "\n")
 print("\n".join(md)[:3000])
