@@ -34,9 +34,10 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 S_VIEWS, IMG = 8, 518
 
 
-def vggt_flops_per_step(S):
-    """algorithmic FLOPs of one S-view call without the track head."""
-    return S * (1017.1 + 1015.5 + 829.9 + 1.7 + 298.5 + 298.6) * 1e9 + 24 * 4 * (S * 1374) ** 2 * 1024
+def vggt_flops_per_step(S, track=True):
+    """algorithmic FLOPs of one S-view call (40.6 TFLOP at S = 8 with the track head on
+    17 query points, 39.6 without)."""
+    return S * (1017.1 + 1015.5 + 829.9 + 1.7 + 298.5 + 298.6 + (132.4 if track else 0.0)) * 1e9 + 24 * 4 * (S * 1374) ** 2 * 1024
 
 
 def main():
@@ -50,17 +51,34 @@ def main():
                          "its own HIP stream (infer.process_multi_view_clip(streams=N)); 1 = one batch per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vp3d", action="store_true", help="skip the VideoPose3D lifter leg (profiling runs)")
-    ap.add_argument("--cpu-views", type=int, default=2, help="views of the bounded CPU-baseline sample")
+    ap.add_argument("--no-track", action="store_true", help="leave the track head out of the step (39.6 instead of 40.6 TFLOP)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the timing of the fp32-accurate (bf16x3) mode")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes, before
+        # anything in this process touches the GPU
+        sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = "WORLD_SIZE" in os.environ and "RANK" in os.environ   # launched by torch.distributed.run
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU is the contract")
+    # SKIMI_BENCH_ONE_GPU=1: rehearsal of the N-rank path on a one-GPU box -- every rank uses cuda:0 and the
+    # collectives run over gloo (RCCL refuses two ranks on one device).  Never a measurement.
+    rehearsal = os.environ.get("SKIMI_BENCH_ONE_GPU") == "1" and use_dist
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
     dev = torch.device("cuda", local_rank)
 
     from skiing_analysis_pytorch_amd import _lib, vggt, weights as W
@@ -79,22 +97,12 @@ def main():
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.rand((B, S_VIEWS, 3, IMG, IMG), generator=g, device=dev, dtype=torch.float32)
-    want = {"camera", "depth", "point"}
-    # 2D keypoints of the 17 joints in every view (the reference reads them from the clip's .pt file)
+    track = not args.no_track
+    want = {"camera", "depth", "point"} | ({"track"} if track else set())
+    # 2D keypoints of the 17 joints in every view (the reference reads them from the clip's .pt file);
+    # the track head's query points are the step's view-0 keypoints in 518-space
     kps = torch.rand((B, S_VIEWS, 17, 2), generator=g, device=dev, dtype=torch.float32) * (IMG - 40) + 20
     from skiing_analysis_pytorch_amd import geometry, parallel
-
-    def step():
-        # VGGT forward (all three heads, as `self.vggt(imgs)` computes them) -> cameras -> DLT
-        # triangulation of the joints over the 8 views -> [B, 17, 3]; under torch.distributed the
-        # per-rank joints are re-assembled with the path's one collective (all-gather over xGMI)
-        out = model(images, want=want)
-        E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (IMG, IMG))
-        joints = geometry.triangulate_joints(K, E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous(), kps)
-        if use_dist:
-            joints = parallel.all_gather_steps(joints, world * B)
-        out["joints3d"] = joints
-        return out
 
     # --streams N: N independent batches per step, one host thread + HIP stream each (what
     # infer.process_multi_view_clip(streams=N) does with the calls of a clip)
@@ -104,9 +112,18 @@ def main():
              for _ in range(NS - 1)]
 
     def step_on(images_k, kps_k):
-        out = model(images_k, want=want)
+        # VGGT forward (all four heads, as `self.vggt(imgs, query_points)` computes them) -> cameras -> DLT
+        # triangulation of the joints over the 8 views -> [B, 17, 3]
+        out = model(images_k, query_points=kps_k[:, 0].contiguous() if track else None, want=want)
         E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (IMG, IMG))
-        out["joints3d"] = geometry.triangulate_joints(K, E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous(), kps_k)
+        out["joints3d_local"] = geometry.triangulate_joints(K, E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous(), kps_k)
+        return out
+
+    def step():
+        out = step_on(images, kps)
+        # under torch.distributed the per-rank joints are re-assembled with the path's one collective
+        # (all-gather over xGMI)
+        out["joints3d"] = parallel.all_gather_steps(out["joints3d_local"], world * B) if use_dist else out["joints3d_local"]
         return out
 
     def step_multi(n_streams):
@@ -132,11 +149,10 @@ def main():
             t_.join()
         for s_ in side:
             main.wait_stream(s_)
-        joints = torch.cat([o["joints3d"] for o in outs])
-        if use_dist:
-            joints = parallel.all_gather_steps(joints, world * n_streams * B)
+        joints = torch.cat([o["joints3d_local"] for o in outs])
         out = outs[0]
-        out["joints3d"] = joints
+        out["joints3d_local"] = joints
+        out["joints3d"] = parallel.all_gather_steps(joints, world * n_streams * B) if use_dist else joints
         return out
 
     step()   # prepares the handle for this frame shape (and is the one-stream warm-up)
@@ -165,6 +181,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out["pose_enc"]).all() and out["joints3d"].shape == (world * NS * B, 17, 3)
+    if use_dist:
+        # the gathered [N*B*streams, 17, 3] tensor must hold every rank's block: each rank checks its own
+        # block bit for bit, rank 0 checks every block against that rank's checksum (outside the timed region)
+        nloc = NS * B
+        mine = out["joints3d"][rank * nloc:(rank + 1) * nloc]
+        assert torch.equal(mine, out["joints3d_local"]), "all-gather: this rank's block differs from its local joints"
+        sums = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(sums, out["joints3d_local"].double().sum().reshape(1))
+        blocks = out["joints3d"].double().reshape(world, -1).sum(dim=1)
+        assert torch.equal(sums, blocks), "all-gather: a rank's block is missing from the gathered joints"
+        assert torch.isfinite(out["joints3d"]).all()
 
     frames = world * args.steps * B * NS
     value = frames / elapsed
@@ -180,13 +207,15 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "bf16",
-        "data": "synthetic",
-        "config": {"workload": "VGGT-1B multi_view_process step: 8 views x 518x518, camera+depth+point heads, "
-                               "pose->cameras + 8-view DLT of 17 joints (+ all-gather of the joints across ranks)",
+        "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if rehearsal else ""),
+        "config": {"workload": "VGGT-1B multi_view_process step (BASELINE config 3): 8 views x 518x518, camera+depth+point"
+                               + ("+track heads (17 query points per step), " if track else " heads, ")
+                               + "pose->cameras + 8-view DLT of 17 joints (+ all-gather of the joints across ranks)",
                    "views": S_VIEWS, "image": IMG, "time_steps_per_call": B, "streams": NS, "parallelism": f"clip-dp{world}",
                    "aggregator_prec": "bf16 MFMA, fp32 accumulate/residual/LayerNorm/softmax",
                    "head_prec": "bf16x3 (fp32-accurate)"},
-        "whole_path_tflops": vggt_flops_per_step(S_VIEWS) * B * NS * args.steps * world / elapsed / 1e12,
+        "whole_path_tflops": vggt_flops_per_step(S_VIEWS, track) * B * NS * args.steps * world / elapsed / 1e12,
+        "tflop_per_step": vggt_flops_per_step(S_VIEWS, track) / 1e12,
     }
     if n.value > 0:
         avg_s = ms.value * 1e-3 / n.value
@@ -195,6 +224,8 @@ def main():
         line["roofline"] = {"kernel": "attn_q64_kernel (global attention, seq 10992, 16 heads x 64)",
                             "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(B),
+                            "traffic_source": "static: profiles/r02_attn_traffic.json (rocprofv3 --pmc passes of this kernel "
+                                              "source, matched by its sha256; null when the kernel changed since)",
                             "avg_launch_us": avg_s * 1e6, "launches": int(n.value),
                             "flops_per_launch": flops_per_launch}
     if rank == 0 and world == 1 and NS > 1 and "roofline" in line:
@@ -210,11 +241,42 @@ def main():
     if rank == 0 and world == 1 and not args.no_vp3d:
         line["vp3d"] = vp3d_leg(dev, cpu=not args.no_cpu_baseline)
     if rank == 0 and cpu_sd is not None:
-        line["cpu_baseline"], line["parity_vs_cpu_oracle"] = cpu_baseline(cpu_sd, cfg, args.cpu_views, model, dev)
+        line["cpu_baseline"], line["mpjpe_vs_cpu_oracle"], line["parity_mode"] = cpu_baseline(
+            cpu_sd, cfg, model, dev, track, not args.no_parity_mode)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run N ranks (one per GPU) as children of
+    `python -m torch.distributed.run` on 127.0.0.1, relay rank 0's JSON line, return non-zero if any
+    rank failed.  This process never initialises the GPU (no exec after HIP init, no device held by
+    the parent)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    got_line = False
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            got_line = True
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and not got_line:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return rc
 
 
 def cpu_threads():
@@ -232,7 +294,7 @@ def vp3d_leg(dev, cpu=True):
     """Second leg of the path (BASELINE configs[0]): the VideoPose3D TemporalModel lifter, receptive
     field 27, 17 COCO joints, 243-frame clips of synthetic 2D keypoints, fp32-accurate mode.  Not part
     of `value`; reported beside it: HIP-event time per call, clips/s, and the achieved fraction of the
-    HBM roofline on the algorithmic bytes (weights once per call + activations once per layer)."""
+    HBM roofline on SURVEY §8(d)'s algorithmic bytes (fp32 weights once per call + B x (input + output))."""
     from skiing_analysis_pytorch_amd import vp3d, weights as W
     from skiing_analysis_pytorch_amd._lib import PREC_BF16X3
     fw = [3, 3, 3]
@@ -242,8 +304,8 @@ def vp3d_leg(dev, cpu=True):
     wbytes = sum(v.numel() * 4 for k, v in sd.items() if k.endswith("weight") and v.dim() == 3)
     res = {"model": "TemporalModel RF 27, 1024 channels, bf16x3 (fp32-accurate), 243-frame clips", "hbm_peak_GBps": 8000.0}
     for B in (1, 64):
-        x = torch.randn(B, 243, 17, 2, device=dev)
-        out = torch.empty(B, 217, 17, 3, device=dev)
+        x = torch.randn(B, 269, 17, 2, device=dev)     # 243 frames edge-padded by the receptive field (generators.py:216-239)
+        out = torch.empty(B, 243, 17, 3, device=dev)
         for _ in range(3):
             m(x, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -254,11 +316,11 @@ def vp3d_leg(dev, cpu=True):
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / n
-        # activations: fp32 [B*L, 1024] written and read once per conv (10 convs, L shrinking 241 -> 217)
-        act = sum(2 * B * L * 1024 * 4 for L in (241, 235, 235, 217, 217)) * 2
+        # algorithmic bytes = fp32 weights once per call + B x (input + output)
+        alg = wbytes + B * (269 * 34 + 243 * 51) * 4
         res[f"clips_{B}"] = {"us_per_call": t * 1e6, "clips_per_s": B / t, "frames_per_s": B * 243 / t,
-                             "algorithmic_GB": (wbytes + act) / 1e9, "achieved_GBps": (wbytes + act) / t / 1e9,
-                             "frac_of_hbm_peak": (wbytes + act) / t / 8e12}
+                             "algorithmic_GB": alg / 1e9, "achieved_GBps": alg / t / 1e9,
+                             "frac_of_hbm_peak": alg / t / 8e12}
     # the receptive-field-243 lifter of BASELINE configs[4] (5 blocks, 67.8 MB of fp32 weights): 485 input
     # frames -> 243 output frames
     fw5 = [3, 3, 3, 3, 3]
@@ -280,10 +342,10 @@ def vp3d_leg(dev, cpu=True):
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / n
-        act = sum(2 * B * L * 1024 * 4 for L in (483, 477, 477, 459, 459, 405, 405, 243, 243)) * 2
+        alg = wbytes5 + B * (485 * 34 + 243 * 51) * 4
         res["rf243"][f"clips_{B}"] = {"us_per_call": t * 1e6, "clips_per_s": B / t, "frames_per_s": B * 243 / t,
-                                      "algorithmic_GB": (wbytes5 + act) / 1e9, "achieved_GBps": (wbytes5 + act) / t / 1e9,
-                                      "frac_of_hbm_peak": (wbytes5 + act) / t / 8e12}
+                                      "algorithmic_GB": alg / 1e9, "achieved_GBps": alg / t / 1e9,
+                                      "frac_of_hbm_peak": alg / t / 8e12}
     del m5, sd5
     if cpu:
         from oracle import vp3d_oracle   # test infrastructure: the timed CPU baseline only
@@ -300,47 +362,104 @@ def vp3d_leg(dev, cpu=True):
     return res
 
 
+def attn_kernel_sha():
+    """sha256 of the roofline kernel's source: ties a committed PMC profile to the kernel it measured"""
+    import hashlib
+    src = Path(__file__).resolve().parent / "skiing_analysis_pytorch_amd" / "csrc" / "attention_q64.hip"
+    return hashlib.sha256(src.read_bytes()).hexdigest()[:16]
+
+
 def pmc_traffic(time_steps):
     """HBM bytes per global-attention launch from the committed rocprofv3 PMC passes
-    (profiles/r01_attn_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE), or None when the
-    profile was taken at another launch shape."""
-    f = Path(__file__).resolve().parent / "profiles" / "r01_attn_traffic.json"
+    (profiles/r02_attn_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/pmc_traffic.py).  A static
+    figure, not measured in this run: returned only when the profile was taken at this launch shape AND
+    on this kernel source (sha256 recorded in the file), otherwise None."""
+    f = Path(__file__).resolve().parent / "profiles" / "r02_attn_traffic.json"
     try:
         d = json.loads(f.read_text())
     except (OSError, ValueError):
         return None
-    return d["hbm_bytes_per_launch"] if d.get("time_steps") == time_steps else None
+    if d.get("time_steps") != time_steps or d.get("kernel_sha") != attn_kernel_sha():
+        return None
+    return d["hbm_bytes_per_launch"]
 
 
-def cpu_baseline(cpu_sd, cfg, views, model, dev):
-    """The oracle (fp32 CPU restatement of the reference, oracle/vggt_oracle.py) on a bounded
-    sample: ONE `views`-view 518x518 step on this host's cores.  An 8-view step costs
-    flops(8)/flops(views) more; the value is scaled by that ratio and the sample says so."""
-    from oracle import vggt_oracle
+def cpu_baseline(cpu_sd, cfg, model, dev, track, parity_mode):
+    """The oracle (fp32 CPU restatement of the reference, oracle/vggt_oracle.py) MEASURED on one full
+    8-view 518x518 step of the benchmarked workload (all heads) on this host's cores -- the bounded sample:
+    about a minute of CPU work.  The same step then goes through the benchmarked HIP model (bf16
+    aggregator) and through the fp32-accurate mode (bf16x3 everywhere), and the error the metric is defined
+    on -- MPJPE (VideoPose3D/common/loss.py:11-17) of the 8-view DLT joints against the joints from the
+    oracle's cameras, on identical 2D keypoints -- is reported for both, with the parity mode's own
+    frames/s.  The oracle is the checker here, outside every timed GPU region."""
+    from oracle import joints_check, vggt_oracle
+    from skiing_analysis_pytorch_amd import geometry, vggt
+    from skiing_analysis_pytorch_amd._lib import PREC_BF16X3
 
     # cores actually granted to this process (the GPU box gives a 1-GPU job a 16-core share;
     # os.cpu_count() reports the whole host and oversubscribes)
     threads = cpu_threads()
-    img = torch.rand((1, views, 3, IMG, IMG), generator=torch.Generator().manual_seed(5))
+    gen = torch.Generator().manual_seed(5)
+    img = torch.rand((1, S_VIEWS, 3, IMG, IMG), generator=gen)
+    q = torch.rand((1, 17, 2), generator=gen) * (IMG - 80) + 40
     d = cfg.to_dict()
-    d["enable_track"] = False
+    d["enable_track"] = bool(track)
     with torch.no_grad():
         t0 = time.perf_counter()
-        ref = vggt_oracle.vggt_forward(cpu_sd, img, d)
+        ref = vggt_oracle.vggt_forward(cpu_sd, img, d, query_points=q if track else None)
         dt = time.perf_counter() - t0
-    ratio = vggt_flops_per_step(S_VIEWS) / vggt_flops_per_step(views)
-    base = {"value": 1.0 / (dt * ratio), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"one {views}-view 518x518 step = {dt:.1f} s measured; 8-view step = x{ratio:.2f} FLOPs (extrapolated)",
+    base = {"value": 1.0 / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"one full 8-view 518x518 step (all heads{', 17 query points' if track else ''}) on the fp32 CPU "
+                      f"oracle = {dt:.1f} s, measured, not extrapolated",
             "measured_seconds": dt}
-    # the same full-size input through the benchmarked HIP model (bf16 aggregator, fp32-accurate
-    # heads) against the fp32 CPU oracle: the checker, outside the timed region
-    got = model(img.to(dev), want={"camera", "depth"})
-    pe = (got["pose_enc"].cpu() - ref["pose_enc"]).abs().max().item()
+    kps, Xw, joints_ref = joints_check.keypoints_from_oracle_cameras(ref["pose_enc"], (IMG, IMG), joints=17, seed=5)
+
+    def joints_of(m):
+        out = m(img.to(dev), query_points=q.to(dev) if track else None, want={"camera", "depth"} | ({"track"} if track else set()))
+        E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (IMG, IMG))
+        j = geometry.triangulate_joints(K, E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous(), kps.to(dev))
+        return out, j.cpu().numpy()
+
+    got, j16 = joints_of(model)
     rel = ((got["depth"].cpu() - ref["depth"]).abs() / (ref["depth"].abs() + 1.0))
-    parity = {"sample": f"VGGT-1B, {views} views x 518x518, synthetic weights; bf16 aggregator vs fp32 CPU oracle",
-              "pose_enc_max_abs_err": pe, "depth_rel_err_median": rel.median().item(),
-              "depth_rel_err_p99": rel.flatten().kthvalue(int(0.99 * rel.numel())).values.item()}
-    return base, parity
+    parity = {"sample": "VGGT-1B, 8 views x 518x518, synthetic weights; joints = 8-view DLT of 17 keypoints projected from "
+                        "known 3D points through the oracle's cameras; reference = the same DLT with the oracle's cameras",
+              "bar": 1e-3, "scene_scale": float(abs(joints_ref).max()),
+              "dlt_conditioning_error": joints_check.conditioning_error(Xw, joints_ref),
+              "bf16_bench_mode": {"mpjpe": joints_check.mpjpe(j16, joints_ref),
+                                  "pose_enc_max_abs_err": (got["pose_enc"].cpu() - ref["pose_enc"]).abs().max().item(),
+                                  "depth_rel_err_median": rel.median().item()}}
+    if track:
+        parity["bf16_bench_mode"]["track_px_err_median"] = (got["track"].cpu() - ref["track"]).abs().median().item()
+    parity["bf16_bench_mode"]["within_bar"] = parity["bf16_bench_mode"]["mpjpe"] <= 1e-3
+    pm = None
+    if parity_mode:
+        m3 = vggt.VGGT(config=cfg, prec=PREC_BF16X3, head_prec=PREC_BF16X3)
+        m3.load_state_dict(cpu_sd)
+        got3, j3 = joints_of(m3)
+        rel3 = ((got3["depth"].cpu() - ref["depth"]).abs() / (ref["depth"].abs() + 1.0))
+        parity["bf16x3_parity_mode"] = {"mpjpe": joints_check.mpjpe(j3, joints_ref),
+                                        "pose_enc_max_abs_err": (got3["pose_enc"].cpu() - ref["pose_enc"]).abs().max().item(),
+                                        "depth_rel_err_max": rel3.max().item()}
+        if track:
+            parity["bf16x3_parity_mode"]["track_px_err_max"] = (got3["track"].cpu() - ref["track"]).abs().max().item()
+        parity["bf16x3_parity_mode"]["within_bar"] = parity["bf16x3_parity_mode"]["mpjpe"] <= 1e-3
+        # the parity mode's own throughput: the same full step (all heads), one 8-view time step per call
+        imgs = img.to(dev)
+        qd = q.to(dev) if track else None
+        want = {"camera", "depth", "point"} | ({"track"} if track else set())
+        m3(imgs, query_points=qd, want=want)
+        torch.cuda.synchronize()
+        n = 3
+        t0 = time.perf_counter()
+        for _ in range(n):
+            m3(imgs, query_points=qd, want=want)
+        torch.cuda.synchronize()
+        dt3 = (time.perf_counter() - t0) / n
+        pm = {"value": 1.0 / dt3, "unit": "frames/s", "ms_per_step": dt3 * 1e3, "time_steps_per_call": 1,
+              "mode": "bf16x3 everywhere (fp32-accurate: the mode that meets the 1e-3 bar), same full step"}
+        del m3
+    return base, parity, pm
 
 
 if __name__ == "__main__":

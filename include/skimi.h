@@ -303,9 +303,9 @@ typedef struct skimi_vggt_outputs {
 /* images: dev f32 [B, S, 3, H, W] in [0, 1]; query_points: dev f32 [B, N, 2] pixels or NULL.
  * Errors mirror the reference: channels != 3 cannot be expressed (the layout fixes 3);
  * H or W not a multiple of patch_size -> SKIMI_ERR_ARG (patch_embed.py:69-70).
- * Concurrency: calls of ONE shape (B, S, H, W) may run at the same time on one handle from several
- * host threads, each with its own workspace and stream, once a first call of that shape has
- * returned (a new shape rebuilds the handle's position / RoPE / UV tables). */
+ * Concurrency: calls of any shapes (B, S, H, W) may run at the same time on one handle from several
+ * host threads, each with its own workspace and stream (the handle's per-shape position / RoPE / UV
+ * tables are a keyed cache of immutable entries, built under a lock on a shape's first call). */
 int skimi_vggt_forward(skimi_vggt*, const float* images, const float* query_points, int32_t B, int32_t S,
                        int32_t H, int32_t W, int32_t n_query, const skimi_vggt_outputs* out,
                        void* workspace, size_t workspace_bytes, void* stream);

@@ -30,6 +30,10 @@ CXXFLAGS = [
     "-Wno-unused-function",
     "-ffp-contract=off",  # keep a*b+c unfused on the host side and in epilogues: parity with torch CPU
 ]
+# Timing ablations of the hot kernels (SKIMI_ATTN_ABL / SKIMI_GEMM256_ABL / SKIMI_X3_ABL: variants with parts of
+# a kernel removed -- their results are WRONG) are compiled only into a profiling build: SKIMI_ABLATIONS=1.
+if os.environ.get("SKIMI_ABLATIONS") == "1":
+    CXXFLAGS.append("-DSKIMI_ABLATIONS")
 
 
 # Per-file extras.  The attention kernels must not get packed-fp32 VALU ops (v_pk_fma_f32,

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const AttnArgs a, int
     const float c2 = a.scale * 1.44269504088896340736f;   // softmax scale folded into exp2
 
     issue(0, 0);
-    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): own LDS-DMA landed, then the barrier (protocol: attention_q64.hip)
+    __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const AttnArgs a, int
             }
         }
 
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) ahead of the barrier, written out
         __syncthreads();
     }
 
@@ -232,17 +234,24 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
     SKIMI_CHECK_ARG(nblk < (1l << 31), "skimi_attention: grid too large");
     const bool prof = prof_armed(PROF_ATTN_BF16, a.seq_k);
     if (prof) prof_before(st);
+    // timing ablations (wrong results) exist only in a -DSKIMI_ABLATIONS build (SKIMI_ABLATIONS=1 python -m ...build)
+#ifdef SKIMI_ABLATIONS
     static const int dbg = getenv("SKIMI_ATTN_ABL") ? atoi(getenv("SKIMI_ATTN_ABL")) : 0;
+#else
+    const int dbg = 0;
+#endif
     // SKIMI_ATTN_Q64: 1 (default) the 64-query-per-wave kernel; 0 this file's 32-query kernel
     static const int q64 = getenv("SKIMI_ATTN_Q64") ? atoi(getenv("SKIMI_ATTN_Q64")) : 1;
     if (q64 != 0) {
         attention_q64_dispatch(a, st);
     } else
     switch (dbg) {
+#ifdef SKIMI_ABLATIONS
 #define SKIMI_ABL_CASE(D) case D: hipLaunchKernelGGL(attn_bf16_kernel<D>, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb); break;
         SKIMI_ABL_CASE(1) SKIMI_ABL_CASE(2) SKIMI_ABL_CASE(3) SKIMI_ABL_CASE(4) SKIMI_ABL_CASE(8) SKIMI_ABL_CASE(12)
         SKIMI_ABL_CASE(15)
 #undef SKIMI_ABL_CASE
+#endif
         default: hipLaunchKernelGGL(attn_bf16_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb);
     }
     if (prof) {

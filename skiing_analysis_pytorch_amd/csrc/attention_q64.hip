@@ -10,9 +10,10 @@
 //   * the two query blocks give the scheduler independent MFMA and VALU work inside one wave
 //     (softmax of block 1 under the PV MFMAs of block 0); the second wave on the SIMD comes from
 //     an independent workgroup (2 workgroups per CU, own barriers);
-//   * softmax on packed fp32 VALU (v_pk_fma_f32 / v_pk_add_f32), the row maximum crosses the two
-//     32-lane halves with one v_permlane32_swap instead of an LDS bpermute, row sums are plain
-//     per-lane partial sums merged once at the end (no ones-matrix MFMAs).
+//   * softmax on SCALAR fp32 VALU ops (packed VOP3P ops do not co-issue with an MFMA in flight:
+//     build.py compiles this file with -fno-slp-vectorize), the row maximum crosses the two 32-lane
+//     halves with one v_permlane32_swap instead of an LDS bpermute, row sums are plain per-lane
+//     partial sums merged once at the end (no ones-matrix MFMAs).
 // Workgroup: 4 waves x 64 queries; K/V tiles of 64 keys double-buffered in LDS by LDS-DMA.
 //
 // Tried on top of this, no gain (2327-2344 us against 2307-2311 for the bench's global-attention launch):
@@ -113,8 +114,14 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
     const float c2 = a.scale * 1.44269504088896340736f;   // softmax scale folded into exp2
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+    // LDS-DMA double buffer, visibility protocol: a wave's global_load_lds writes land in LDS when ITS vmcnt
+    // reaches 0, so every wave waits vmcnt(0) on its own DMA and only then enters the workgroup barrier; after
+    // the barrier all four waves' shares of the tile are in LDS.  The wait is written out (not left to how
+    // hipcc lowers __syncthreads(); gfx950 barriers do not wait for memory counters by themselves), and
+    // tests/test_abi.py greps the emitted ISA for `s_waitcnt vmcnt(0)` ahead of every s_barrier of this kernel.
     issue(0, 0);
-    __syncthreads();   // drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
@@ -236,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
                 }
         }
 
-        if (dbg & 1) __builtin_amdgcn_s_waitcnt(0x0F70); else
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of tile kt+1 has landed in LDS
+        if (!(dbg & 1)) __syncthreads();
     }
 
 #pragma unroll
@@ -262,7 +269,11 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
 void attention_q64_dispatch(const AttnArgs& a, hipStream_t st) {
     const int nqb = (int)cdiv(a.seq_q, 256);
     const long nblk = (long)nqb * a.heads * a.batch;
+#ifdef SKIMI_ABLATIONS   // timing ablations (wrong results): only in a -DSKIMI_ABLATIONS build
     static const int dbg = getenv("SKIMI_ATTN_ABL") ? atoi(getenv("SKIMI_ATTN_ABL")) : 0;
+#else
+    const int dbg = 0;
+#endif
     // SKIMI_ATTN_LDSPAD (bytes of unused dynamic LDS): occupancy experiments, e.g. 65536 -> one workgroup per CU
     static const size_t pad = getenv("SKIMI_ATTN_LDSPAD") ? (size_t)atol(getenv("SKIMI_ATTN_LDSPAD")) : 0;
     if (pad) {
@@ -275,9 +286,11 @@ void attention_q64_dispatch(const AttnArgs& a, hipStream_t st) {
         return;
     }
     switch (dbg) {
+#ifdef SKIMI_ABLATIONS
         case 1: hipLaunchKernelGGL(attn_q64_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb); break;
         case 2: hipLaunchKernelGGL(attn_q64_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb); break;
         case 3: hipLaunchKernelGGL(attn_q64_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb); break;
+#endif
         default: hipLaunchKernelGGL(attn_q64_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, a, nqb);
     }
 }

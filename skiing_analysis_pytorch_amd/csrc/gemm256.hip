@@ -744,8 +744,11 @@ static int launch256w4(GemmArgs& a, hipStream_t st) {
 // pick the tile height (192 or 256 rows) that wastes the fewest CU-rounds for this shape:
 // one workgroup per CU, so time ~ ceil(tiles / 256) * (rows per tile)
 int gemm256_launch(GemmArgs& a, hipStream_t st) {
-    const int dbg = SKIMI_ENV_INT("SKIMI_GEMM256_ABL", 0);
-    a.dbg = dbg;
+#ifdef SKIMI_ABLATIONS   // timing ablations (wrong results): only in a -DSKIMI_ABLATIONS build
+    a.dbg = SKIMI_ENV_INT("SKIMI_GEMM256_ABL", 0);
+#else
+    a.dbg = 0;
+#endif
     auto cost = [&](int bm) {
         const long tiles = cdiv(a.M, bm) * cdiv(a.N, 256);
         return (double)cdiv(tiles, 256) * bm;

@@ -845,19 +845,19 @@ int gemm_x3dma_launch(GemmArgs& a, const skimi_gemm_desc* d, hipStream_t st) {
         if (a.a_mode == 1) return launch_x3w4n<1>(a, pl, st);
         return launch_x3w4n<2>(a, pl, st);
     }
+#ifdef SKIMI_ABLATIONS   // timing ablations (wrong results): only in a -DSKIMI_ABLATIONS build
     if (a.a_mode == 0) {
-        static const int abl = getenv("SKIMI_X3_ABL") ? atoi(getenv("SKIMI_X3_ABL")) : 0;   // timing ablations, plain rows only
+        static const int abl = getenv("SKIMI_X3_ABL") ? atoi(getenv("SKIMI_X3_ABL")) : 0;
         switch (abl) {
             case 1: return launch_x3w4<0, 1>(a, pl, st);
             case 2: return launch_x3w4<0, 2>(a, pl, st);
             case 3: return launch_x3w4<0, 3>(a, pl, st);
             case 5: return launch_x3w4<0, 5>(a, pl, st);
             case 6: return launch_x3w4<0, 6>(a, pl, st);
-            default: return launch_x3w4<0>(a, pl, st);
+            default: break;
         }
     }
-    if (a.a_mode == 1) return launch_x3w4<1>(a, pl, st);
-    {
+    if (a.a_mode == 2) {
         static const int abl = getenv("SKIMI_X3_ABL") ? atoi(getenv("SKIMI_X3_ABL")) : 0;
         switch (abl) {
             case 1: return launch_x3w4<2, 1>(a, pl, st);
@@ -868,6 +868,9 @@ int gemm_x3dma_launch(GemmArgs& a, const skimi_gemm_desc* d, hipStream_t st) {
             default: break;
         }
     }
+#endif
+    if (a.a_mode == 0) return launch_x3w4<0>(a, pl, st);
+    if (a.a_mode == 1) return launch_x3w4<1>(a, pl, st);
     return launch_x3w4<2>(a, pl, st);
 }
 

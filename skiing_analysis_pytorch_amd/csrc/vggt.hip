@@ -16,7 +16,9 @@
 #include <string.h>
 
 #include <map>
+#include <memory>
 #include <string>
+#include <tuple>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -89,6 +91,21 @@ struct Arena {
 
 struct UvTab { int w, h, C; float* tx; float* ty; };
 
+// Per-shape constant tables (RoPE positions and cos/sin tables, the DPT heads' UV embeddings): one
+// immutable entry per (frames, H, W), built on first use and kept until the handle is destroyed, so
+// that forwards of ANY shapes may be in flight on one handle at the same time.
+struct ShapeTabs {
+    int* pos = nullptr;             // int32 [F*P, 2]
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    int rope_npos = 0;
+    const float* dino_pos = nullptr;   // DINOv2 pos_embed of this frame size (the model's own or a registered resize)
+    std::vector<UvTab> uv;
+    std::vector<void*> owned;
+    ~ShapeTabs() {
+        for (void* p : owned) (void)hipFree(p);
+    }
+};
+
 #define TRACK_PART 1
 #include "track_impl.inc"
 #undef TRACK_PART
@@ -112,15 +129,9 @@ struct skimi_vggt {
     CamW cam;
     DptW depth, point, trackf;
     TrackW track;
-    // per-resolution tables (prepare())
-    int prepH = 0, prepW = 0, prepF = 0;
-    std::mutex prep_mu;             // guards prepare(); see skimi_vggt_forward
-    std::atomic<int> inflight{0};   // forward calls between their prepare() and their return
-    int* pos = nullptr;             // int32 [F*P, 2]
-    float *rope_cos = nullptr, *rope_sin = nullptr;
-    int rope_npos = 0;
-    std::vector<UvTab> uv;
-    std::vector<void*> prep_owned;
+    // per-shape tables: keyed cache, entries immutable once published (prepare())
+    std::mutex prep_mu;             // guards the map; the entries themselves are read-only
+    std::map<std::tuple<int, int, int>, std::unique_ptr<ShapeTabs>> tabs;   // (F, H, W) ->
 };
 
 namespace {
@@ -331,6 +342,7 @@ struct Packer {
 struct Ctx {
     skimi_vggt* h;
     hipStream_t st;
+    const ShapeTabs* tabs = nullptr;   // this call's shape tables (null in a dry run)
     Arena ar;
     int rc = SKIMI_OK;
     void* slab = nullptr;      // split-K scratch
@@ -401,8 +413,8 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
         c.gemm(d);
     }
     if (!c.rc && !c.dry() && (w.qn_w || rope)) {
-        c.rc = qknorm_rope_launch(b.qkv, adt, M, heads, w.qn_w, w.qn_b, w.kn_w, w.kn_b, 1e-5f, rope ? c.h->pos : nullptr,
-                                  c.h->rope_cos, c.h->rope_sin, c.h->rope_npos, c.st);
+        c.rc = qknorm_rope_launch(b.qkv, adt, M, heads, w.qn_w, w.qn_b, w.kn_w, w.kn_b, 1e-5f, rope ? c.tabs->pos : nullptr,
+                                  c.tabs->rope_cos, c.tabs->rope_sin, c.tabs->rope_npos, c.st);
     }
     if (!c.rc && !c.dry()) c.rc = attention_launch(b.qkv, b.ao, adt, batch, seq, heads, C / heads, c.st);
     {
@@ -423,7 +435,8 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
     }
 }
 
-const UvTab* find_uv(const skimi_vggt* h, int w, int hh, int C) {
+const UvTab* find_uv(const ShapeTabs* h, int w, int hh, int C) {
+    if (!h) return nullptr;
     for (const auto& t : h->uv)
         if (t.w == w && t.h == hh && t.C == C) return &t;
     return nullptr;
@@ -486,7 +499,7 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
                 c.gemm(d);
             }
             if (w.pos_embed && !c.rc && !c.dry()) {
-                const UvTab* t = find_uv(c.h, pw, ph, w.oc[i]);
+                const UvTab* t = find_uv(c.tabs, pw, ph, w.oc[i]);
                 if (!t) { set_error("uv table missing"); c.rc = SKIMI_ERR_STATE; }
                 else c.rc = add_uv_pos_launch(t0, adt, t->tx, t->ty, F, ph, pw, w.oc[i], c.st);
             }
@@ -628,7 +641,7 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
         c.gemm(d);
     }
     const int Ho = ph * c.h->cfg.patch_size / w.down_ratio, Wo = pw * c.h->cfg.patch_size / w.down_ratio;
-    const UvTab* uvt = w.pos_embed ? find_uv(c.h, Wo, Ho, f2) : nullptr;
+    const UvTab* uvt = w.pos_embed ? find_uv(c.tabs, Wo, Ho, f2) : nullptr;
     if (w.pos_embed && !uvt && !c.rc && !c.dry()) { set_error("uv table missing"); c.rc = SKIMI_ERR_STATE; }
     static const int no_direct = getenv("SKIMI_CONV_DIRECT") ? !atoi(getenv("SKIMI_CONV_DIRECT")) : 0;   // A/B timing
     const bool direct = !w.feature_only && w.oc2a_direct != nullptr && adt == SKIMI_F32 && !no_direct;
@@ -720,21 +733,31 @@ void run_camera(Ctx& c, const CamW& w, const float* sf, const float* sg, int B, 
     c.ar.release(mk);
 }
 
-int prepare(skimi_vggt* h, int F, int S, int H, int W) {
-    if (h->prepH == H && h->prepW == W && h->prepF == F) return SKIMI_OK;
+// Looks the (F, H, W) entry up or builds it.  Called with h->prep_mu held.  A build that fails part-way
+// publishes nothing (the half-built entry frees its device buffers on the way out).
+int prepare(skimi_vggt* h, int F, int S, int H, int W, const ShapeTabs** out) {
+    const auto key = std::make_tuple(F, H, W);
+    auto it = h->tabs.find(key);
+    if (it != h->tabs.end()) {
+        *out = it->second.get();
+        return SKIMI_OK;
+    }
     (void)S;
-    for (void* p : h->prep_owned) (void)hipFree(p);
-    h->prep_owned.clear();
-    h->uv.clear();
+    std::unique_ptr<ShapeTabs> tabs(new ShapeTabs());
+    ShapeTabs* t_ = tabs.get();
     const skimi_vggt_config& cfg = h->cfg;
     const int p = cfg.patch_size, ph = H / p, pw = W / p, nsp = 1 + cfg.num_register_tokens, P = nsp + ph * pw;
     auto up = [&](const void* src, size_t bytes, void** dst) -> int {
         SKIMI_HIP(hipMalloc(dst, bytes));
-        h->prep_owned.push_back(*dst);
+        t_->owned.push_back(*dst);
         SKIMI_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         return SKIMI_OK;
     };
     int rc;
+    if (cfg.use_dino) {
+        const bool native = H == W && H == cfg.dino_img_size;
+        t_->dino_pos = native ? h->dino_pos : h->dino_pos_alt.at({H, W});   // presence checked by check_shape
+    }
     // positions: (y, x) + 1 for patches, 0 for the special tokens (rope.py:39-59, aggregator.py:219-228)
     std::vector<int> pos((size_t)F * P * 2, 0);
     for (int f = 0; f < F; ++f)
@@ -744,7 +767,7 @@ int prepare(skimi_vggt* h, int F, int S, int H, int W) {
                 pos[i] = y + 1;
                 pos[i + 1] = x + 1;
             }
-    if ((rc = up(pos.data(), pos.size() * 4, (void**)&h->pos))) return rc;
+    if ((rc = up(pos.data(), pos.size() * 4, (void**)&t_->pos))) return rc;
     // RoPE tables (rope.py:86-117), fp32 arithmetic as torch: 1/100^(i/16), pos*inv_freq, cos/sin
     const int npos = std::max(ph, pw) + 1;
     std::vector<float> cs((size_t)npos * 16), sn((size_t)npos * 16);
@@ -757,12 +780,12 @@ int prepare(skimi_vggt* h, int F, int S, int H, int W) {
             sn[(size_t)q * 16 + i] = sinf(a);
         }
     }
-    if ((rc = up(cs.data(), cs.size() * 4, (void**)&h->rope_cos))) return rc;
-    if ((rc = up(sn.data(), sn.size() * 4, (void**)&h->rope_sin))) return rc;
-    h->rope_npos = npos;
+    if ((rc = up(cs.data(), cs.size() * 4, (void**)&t_->rope_cos))) return rc;
+    if ((rc = up(sn.data(), sn.size() * 4, (void**)&t_->rope_sin))) return rc;
+    t_->rope_npos = npos;
     // UV sin/cos tables (heads/utils.py:11-109 via dpt_head.py:249-259), float64 then float, x 0.1
     auto add_uv = [&](int w, int hh, int C) -> int {
-        if (find_uv(h, w, hh, C)) return SKIMI_OK;
+        if (find_uv(t_, w, hh, C)) return SKIMI_OK;
         const double aspect = (double)W / (double)H;
         const double diag = sqrt(aspect * aspect + 1.0);
         const double sx = aspect / diag, sy = 1.0 / diag;
@@ -788,7 +811,7 @@ int prepare(skimi_vggt* h, int F, int S, int H, int W) {
         int r2;
         if ((r2 = up(tx.data(), tx.size() * 4, (void**)&t.tx))) return r2;
         if ((r2 = up(ty.data(), ty.size() * 4, (void**)&t.ty))) return r2;
-        h->uv.push_back(t);
+        t_->uv.push_back(t);
         return SKIMI_OK;
     };
     if (cfg.enable_depth || cfg.enable_point) {
@@ -796,7 +819,8 @@ int prepare(skimi_vggt* h, int F, int S, int H, int W) {
             if ((rc = add_uv(pw, ph, cfg.dpt_out_channels[i]))) return rc;
         if ((rc = add_uv(pw * p, ph * p, cfg.dpt_features / 2))) return rc;
     }
-    h->prepH = H; h->prepW = W; h->prepF = F;
+    *out = t_;
+    h->tabs[key] = std::move(tabs);
     return SKIMI_OK;
 }
 
@@ -846,7 +870,8 @@ int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query,
             if (cfg.use_dino) {
                 // + pos_embed[1 + p] (vision_transformer.py:221), broadcast over frames
                 const bool native = H == W && H == cfg.dino_img_size;
-                d.resid = native ? h->dino_pos : h->dino_pos_alt.at({H, W}); d.ldr = C;
+                (void)native;
+                d.resid = c.tabs ? c.tabs->dino_pos : h->dino_pos; d.ldr = C;   // dry run: any non-null pointer
                 d.resid_rows_per_batch = np; d.resid_batch_stride = 0; d.resid_row_off = 1;
             }
             c.gemm(d);
@@ -938,7 +963,7 @@ void skimi_vggt_destroy(skimi_vggt* h) {
     if (!h) return;
     for (auto& kv : h->raw) (void)hipFree(kv.second.first);
     for (void* p : h->owned) (void)hipFree(p);
-    for (void* p : h->prep_owned) (void)hipFree(p);
+    h->tabs.clear();
     for (auto& kv : h->dino_pos_alt) (void)hipFree(kv.second);
     delete h;
 }
@@ -973,8 +998,19 @@ int skimi_vggt_set_pos_embed(skimi_vggt* h, int32_t H, int32_t W, const float* p
         set_error("skimi_vggt_set_pos_embed: copy failed: %s", hipGetErrorString(e));
         return SKIMI_ERR_HIP;
     }
+    // published under the handle's table lock; a table registered again for the same size replaces the
+    // CONTENTS of the existing buffer (its address stays valid for forwards already enqueued)
+    std::lock_guard<std::mutex> lk(h->prep_mu);
     auto it = h->dino_pos_alt.find({H, W});
-    if (it != h->dino_pos_alt.end()) (void)hipFree(it->second);
+    if (it != h->dino_pos_alt.end()) {
+        e = hipMemcpy(it->second, d, n * 4, hipMemcpyDeviceToDevice);
+        (void)hipFree(d);
+        if (e != hipSuccess) {
+            set_error("skimi_vggt_set_pos_embed: copy failed: %s", hipGetErrorString(e));
+            return SKIMI_ERR_HIP;
+        }
+        return SKIMI_OK;
+    }
     h->dino_pos_alt[{H, W}] = d;
     return SKIMI_OK;
 }
@@ -1073,11 +1109,13 @@ static int check_shape(const skimi_vggt* h, int B, int S, int H, int W) {
     // patch_embed.py:69-70
     SKIMI_CHECK_ARG(H > 0 && H % p == 0, "Input image height %d is not a multiple of patch height %d", H, p);
     SKIMI_CHECK_ARG(W > 0 && W % p == 0, "Input image width %d is not a multiple of patch width: %d", W, p);
-    if (h->cfg.use_dino && !(H == W && H == h->cfg.dino_img_size))
+    if (h->cfg.use_dino && !(H == W && H == h->cfg.dino_img_size)) {
+        std::lock_guard<std::mutex> lk(const_cast<skimi_vggt*>(h)->prep_mu);
         SKIMI_CHECK_ARG(h->dino_pos_alt.count({H, W}) != 0,
                         "DINOv2 pos_embed for %dx%d (model built for %d) has not been registered: call "
                         "skimi_vggt_set_pos_embed with the bicubic-antialias resized table first", H, W,
                         h->cfg.dino_img_size);
+    }
     return SKIMI_OK;
 }
 
@@ -1106,25 +1144,15 @@ int skimi_vggt_forward(skimi_vggt* h, const float* images, const float* query_po
     }
     int rc;
     if ((rc = check_shape(h, B, S, H, W))) return rc;
-    // Calls of one shape may run at the same time from several host threads (own workspace and
-    // stream each).  A new shape rebuilds the handle's tables: refused while another call is still
-    // enqueueing (the hipFree inside prepare() waits for work already on the device).
-    struct InFlight {
-        skimi_vggt* h;
-        ~InFlight() { h->inflight.fetch_sub(1); }
-    };
+    // Calls of any shapes may run at the same time from several host threads (own workspace and stream
+    // each): the per-shape tables are a keyed cache of immutable entries that live as long as the handle.
+    const ShapeTabs* tabs = nullptr;
     {
         std::lock_guard<std::mutex> lk(h->prep_mu);
-        const bool same = h->prepH == H && h->prepW == W && h->prepF == B * S;
-        if (!same && h->inflight.load() > 0) {
-            set_error("skimi_vggt_forward: a call with another frame shape is in flight on this handle");
-            return SKIMI_ERR_STATE;
-        }
-        if ((rc = prepare(h, B * S, S, H, W))) return rc;
-        h->inflight.fetch_add(1);
+        if ((rc = prepare(h, B * S, S, H, W, &tabs))) return rc;
     }
-    InFlight guard{h};
     Ctx c{h, (hipStream_t)stream};
+    c.tabs = tabs;
     c.ar.base = (char*)workspace;
     c.ar.cap = workspace_bytes;
     // refuse before launching anything if the arena cannot hold the plan

@@ -206,10 +206,6 @@ def process_multi_view_clip(model: VGGT, frames: torch.Tensor, keypoints: torch.
         b = min(a + steps_per_call, hi)
         idx = [min(i, T - 1) for i in range(a, b)]          # padded steps repeat the last one
         n = len(idx)
-        if n_par > 1:
-            # concurrent calls on one handle must all have one shape (the handle's per-shape tables are
-            # rebuilt when it changes): a short last chunk is filled up and cut again below
-            idx = idx + [idx[-1]] * (steps_per_call - n)
         out = model(frames[idx], want=want)
         E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (H, W))
         R, t = E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous()
@@ -224,7 +220,7 @@ def process_multi_view_clip(model: VGGT, frames: torch.Tensor, keypoints: torch.
 
         dev = frames.device
         main = torch.cuda.current_stream(dev)
-        results[0] = one_call(starts[0])    # the first call prepares the handle for this frame shape
+        results[0] = one_call(starts[0])    # sizes this stream's workspace before the side streams start
         side = _side_streams(dev, n_par)
         errors = []
 

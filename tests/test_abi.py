@@ -73,3 +73,44 @@ def test_cpu_tensor_rejected():
     assert m.receptive_field() == 27
     with pytest.raises(_lib.SkimiError):
         m(torch.zeros(1, 27, 17, 2))
+
+
+@pytest.mark.parametrize("src,kernel", [("attention_q64.hip", "attn_q64_kernel"), ("attention_bf16.hip", "attn_bf16_kernel")])
+def test_lds_dma_barriers_wait_for_vmcnt0(src, kernel):
+    """The LDS-DMA double buffer of the attention kernels is only correct if every wave has waited
+    `vmcnt(0)` on its own global_load_lds before it enters the workgroup barrier (a gfx950 barrier does not
+    wait for memory counters by itself).  The source writes the wait out; this checks the EMITTED ISA of
+    the build's own flags: every s_barrier of the kernel is directly preceded by an s_waitcnt vmcnt(0)
+    with no LDS-DMA issued in between."""
+    import shutil
+    import subprocess
+
+    from skiing_analysis_pytorch_amd import build as b
+
+    if shutil.which(b.HIPCC) is None and not Path(b.HIPCC).exists():
+        pytest.skip("hipcc not available")
+    flags = [f for f in b.CXXFLAGS if f != "-fPIC"] + b.EXTRA_FLAGS.get(src, [])
+    r = subprocess.run([b.HIPCC, *flags, "-S", "--offload-device-only", str(b.CSRC / src), "-o", "-"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    body, inside = [], False
+    for ln in r.stdout.splitlines():
+        if re.match(rf"^_ZN5skimi\d+{kernel}ILi0EE.*:", ln):
+            inside = True
+            continue
+        if inside:
+            if "s_endpgm" in ln:
+                break
+            ins = ln.strip()
+            if ins and not ins.startswith((";", ".")):
+                body.append(ins)
+    barriers = [i for i, ins in enumerate(body) if ins.startswith("s_barrier")]
+    assert len(barriers) >= 2, "expected the prologue barrier and the loop barrier"
+    assert any("global_load_lds" in ins for ins in body)
+    for i in barriers:
+        j = i - 1
+        while j >= 0 and not body[j].startswith("s_waitcnt"):
+            assert "global_load_lds" not in body[j], "LDS-DMA issued between the last wait and the barrier"
+            assert i - j <= 4, f"no s_waitcnt directly ahead of the s_barrier: {body[max(0, i - 5):i + 1]}"
+            j -= 1
+        assert j >= 0 and "vmcnt(0)" in body[j], body[max(0, i - 5):i + 1]

@@ -1,0 +1,105 @@
+"""Parity AT THE BENCHMARKED SHAPE: VGGT-1B, S = 8 views x 518 x 518 (global attention over 10 992
+tokens), B = 2 time steps per call (batch > 1 and the long sequence both live), all four heads
+(17 query points per step: BASELINE config 3), synthetic weights shared with the fp32 CPU oracle.
+
+  * PREC_BF16X3 everywhere (the parity mode): every output <= 1e-3 against the oracle, and the MPJPE
+    (VideoPose3D/common/loss.py:11-17) of the 8-view DLT joints from the HIP cameras against the joints
+    from the oracle's cameras on identical 2D keypoints <= 1e-3.
+  * PREC_BF16 aggregator (the benchmark mode = the reference's own GPU autocast precision,
+    vggt/vggt/infer.py:78-84): the same MPJPE is measured and bounded; it does NOT meet 1e-3 (bf16
+    operands put ~5e-3 on pose_enc, which the synthetic model's cameras -- FoV > pi, a 0.9-unit
+    baseline seen from 3 units -- amplify ~10x), which is why bench.py reports both modes.
+
+The oracle runs once per module (two S = 8 steps, about a minute and a half on the GPU box's 16 cores).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import joints_check, vggt_oracle
+from skiing_analysis_pytorch_amd import geometry, vggt, weights as W
+from skiing_analysis_pytorch_amd._lib import PREC_BF16, PREC_BF16X3
+
+pytestmark = pytest.mark.gpu
+
+B, S, IMG, NQ = 2, 8, 518, 17
+
+
+@pytest.fixture(scope="module")
+def bench_shape():
+    cfg = W.VGGTConfig()                                    # VGGT-1B, all heads
+    sd = W.make_vggt_state_dict(cfg, seed=0, device="cuda")
+    cpu_sd = {k: v.cpu() for k, v in sd.items()}
+    g = torch.Generator().manual_seed(1234)
+    images = torch.rand((B, S, 3, IMG, IMG), generator=g)
+    queries = torch.rand((B, NQ, 2), generator=g) * (IMG - 80) + 40      # view-0 keypoints in 518-space
+    try:
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
+    with torch.no_grad():
+        ref = vggt_oracle.vggt_forward(cpu_sd, images, cfg.to_dict(), query_points=queries)
+    kps, Xw, joints_ref = joints_check.keypoints_from_oracle_cameras(ref["pose_enc"], (IMG, IMG), joints=17, seed=5)
+    assert joints_check.conditioning_error(Xw, joints_ref) < 1e-4      # the DLT systems are well conditioned
+    return dict(cfg=cfg, sd=sd, images=images, queries=queries, ref=ref, kps=kps, joints_ref=joints_ref)
+
+
+def _joints(out, kps):
+    E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (IMG, IMG))
+    return geometry.triangulate_joints(K, E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous(), kps.cuda()).cpu().numpy()
+
+
+def _rel(got, ref):
+    return ((got.cpu() - ref).abs() / (ref.abs() + 1.0)).max().item()
+
+
+def test_parity_mode_every_output_at_bench_shape(bench_shape):
+    s = bench_shape
+    m = vggt.VGGT(config=s["cfg"], prec=PREC_BF16X3, head_prec=PREC_BF16X3)
+    m.load_state_dict(s["sd"])
+    out = m(s["images"].cuda(), query_points=s["queries"].cuda())
+    torch.cuda.synchronize()
+    ref = s["ref"]
+    for i in range(4):
+        assert (out["pose_enc_list"][i].cpu() - ref["pose_enc_list"][i]).abs().max().item() < 1e-3
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
+        assert out[k].shape == ref[k].shape
+        assert _rel(out[k], ref[k]) < 1e-3, k
+    # the second time step of the batch is its own scene: it must not be a copy of the first
+    assert (out["pose_enc"][0] - out["pose_enc"][1]).abs().max().item() > 1e-4
+    # track head at full size (7 correlation levels, 4 iterations, 6 + 18 blocks, 64 virtual tracks,
+    # 17 queries); tolerance in pixels as for the tiny golden (test_vggt_gpu.py)
+    assert out["track"].shape == ref["track"].shape == (B, S, NQ, 2)
+    assert (out["track"].cpu() - ref["track"]).abs().max().item() < 5e-2
+    assert (out["vis"].cpu() - ref["vis"]).abs().max().item() < 5e-3
+    assert (out["conf"].cpu() - ref["conf"]).abs().max().item() < 5e-3
+    assert torch.allclose(out["track"][:, 0].cpu(), s["queries"], atol=1e-4)
+    # the metric's quantity: 3D joints
+    e = joints_check.mpjpe(_joints(out, s["kps"]), s["joints_ref"])
+    print(f"parity mode (bf16x3): MPJPE of the DLT joints vs the CPU oracle = {e:.3e}")
+    assert e < 1e-3
+
+
+def test_bench_mode_joints_mpjpe_at_bench_shape(bench_shape):
+    s = bench_shape
+    m = vggt.VGGT(config=s["cfg"], prec=PREC_BF16, head_prec=PREC_BF16X3)
+    m.load_state_dict(s["sd"])
+    out = m(s["images"].cuda(), query_points=s["queries"].cuda())
+    torch.cuda.synchronize()
+    ref = s["ref"]
+    for k in ("pose_enc", "depth", "world_points", "track"):
+        assert torch.isfinite(out[k]).all(), k
+    pe = (out["pose_enc"].cpu() - ref["pose_enc"]).abs().max().item()
+    e = joints_check.mpjpe(_joints(out, s["kps"]), s["joints_ref"])
+    scale = float(np.abs(s["joints_ref"]).max())
+    print(f"bench mode (bf16 aggregator): pose_enc max abs err {pe:.3e}, joints MPJPE {e:.3e} (scene scale {scale:.2f})")
+    # bf16 operands: ~5e-3 on pose_enc; documented, bounded, NOT within the 1e-3 bar (see module docstring)
+    assert pe < 3e-2
+    assert e < 0.15
+    # dense outputs keep bf16-level agreement at this size too (an indexing bug would show as O(1))
+    rel = (out["depth"].cpu() - ref["depth"]).abs() / (ref["depth"].abs() + 1.0)
+    assert rel.median().item() < 2e-2
+    # a tracked point moves with the features: bf16 features shift tracks by a fraction of a pixel
+    assert (out["track"].cpu() - ref["track"]).abs().median().item() < 2.0
