@@ -30,16 +30,46 @@ def _to_numpy_xy(kpts) -> np.ndarray:
     return a[..., :2].astype(np.float32)
 
 
+def read_video_frames(video_file_path) -> torch.Tensor:
+    """[T, H, W, 3] uint8 RGB frames of a video file, as the reference's
+    `read_video(path, pts_unit="sec", output_format="THWC")[0]` (vggt/load.py:292).  Video decode is
+    outside this build: an installed torchvision / OpenCV is used when there is one, and the
+    error says what to do otherwise."""
+    try:
+        from torchvision.io import read_video   # the reference's own decoder
+        return read_video(str(video_file_path), pts_unit="sec", output_format="THWC")[0]
+    except ImportError:
+        pass
+    try:
+        import cv2
+    except ImportError:
+        raise RuntimeError(f"no video decoder in this environment (torchvision / cv2) for {video_file_path}: embed the "
+                           "frames in the .pt file (key 'frames', [T,H,W,3] uint8, as prepare_dataset can) or pass frames=")
+    cap, out = cv2.VideoCapture(str(video_file_path)), []
+    while True:
+        ok, fr = cap.read()
+        if not ok:
+            break
+        out.append(torch.from_numpy(cv2.cvtColor(fr, cv2.COLOR_BGR2RGB)))
+    cap.release()
+    return torch.stack(out)
+
+
 def load_info(pt_file_path, frames: Optional[torch.Tensor] = None, assume_normalized: Optional[bool] = None,
-              clip_bbox_to_image: bool = True, dtype=np.float32) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, Optional[torch.Tensor]]:
+              clip_bbox_to_image: bool = True, dtype=np.float32, video_file_path=None
+              ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, Optional[torch.Tensor]]:
     """vggt/load.py:268-370.  Returns (keypoints_xy [T,K,2] pixels, keypoints_score [T,K],
-    bboxes_xyxy [T,4|N,4] pixels, bbox_scores, frames [T,H,W,3] uint8 | None)."""
+    bboxes_xyxy [T,4|N,4] pixels, bbox_scores, frames [T,H,W,3] uint8 | None).  Frames: the `frames`
+    argument, else the `.pt` file's own `frames`, else decoded from `video_file_path` when a decoder is
+    installed (the reference always decodes the video)."""
     data = _load_pt(pt_file_path)
     if "detectron2" not in data:
         raise KeyError(f"pt file missing 'detectron2' root: {pt_file_path}")
     d2 = data["detectron2"]
     if frames is None and "frames" in data and data["frames"] is not None:
         frames = data["frames"]
+    if frames is None and video_file_path is not None and Path(video_file_path).exists():
+        frames = read_video_frames(video_file_path)
     if frames is not None:
         H, W = int(frames.shape[1]), int(frames.shape[2])
     elif "img_shape" in data:

@@ -40,62 +40,64 @@ def softmax2(a: np.ndarray, b: np.ndarray):
     return ea / s, eb / s
 
 
+def _row_ok(X: np.ndarray) -> np.ndarray:
+    """[..., J, 3] -> [..., J]: the joint has three finite coordinates"""
+    return np.isfinite(X).all(axis=-1)
+
+
+def _select_rows(code: np.ndarray, *candidates: np.ndarray) -> np.ndarray:
+    """row j of the result = row j of candidates[code[j]]; code 0 = missing (NaN row)"""
+    stack = np.stack((np.full_like(candidates[0], np.nan),) + candidates)          # [1 + n, J, 3]
+    return np.take_along_axis(stack, code[None, :, None], axis=0)[0]
+
+
 def fuse_frame_3d(Xl: np.ndarray, Xr: np.ndarray, q_l: np.ndarray, q_r: np.ndarray) -> np.ndarray:
-    """fuse.py:289-325: per-joint softmax-weighted fusion of two [J,3] estimates in the SAME frame;
-    a joint finite on one side only is taken from that side; missing on both stays NaN."""
+    """fuse/fuse.py:289-325 in array form: two [J,3] estimates of the SAME frame, per-joint qualities q.
+    Every joint is one of four cases, encoded as (left present) + 2 (right present):
+    0 missing -> NaN, 1 -> left, 2 -> right, 3 -> softmax2-weighted blend (wl Xl + wr Xr) / (wl + wr + EPS)."""
     Xl, Xr = np.asarray(Xl, dtype=np.float64), np.asarray(Xr, dtype=np.float64)
-    ok_l = np.all(np.isfinite(Xl), axis=1)
-    ok_r = np.all(np.isfinite(Xr), axis=1)
-    wl, wr = softmax2(q_l, q_r)
-    fused = np.full_like(Xl, np.nan)
-    both = ok_l & ok_r
-    fused[both] = (wl[both, None] * Xl[both] + wr[both, None] * Xr[both]) / (wl[both, None] + wr[both, None] + EPS)
-    only_l = ok_l & ~ok_r
-    fused[only_l] = Xl[only_l]
-    only_r = ok_r & ~ok_l
-    fused[only_r] = Xr[only_r]
-    return fused
+    wl, wr = (w[:, None] for w in softmax2(q_l, q_r))
+    with np.errstate(invalid="ignore"):
+        blend = (wl * Xl + wr * Xr) / (wl + wr + EPS)
+    return _select_rows(_row_ok(Xl).astype(np.intp) + 2 * _row_ok(Xr), Xl, Xr, blend)
+
+
+# fuse/fuse.py:353-371: base smoothing factor per MHR-70 joint id, as a multiple of `alpha` -- eyes and neck
+# smoother, feet and hands more responsive, everything else (limbs included) at alpha itself
+_ALPHA_FACTOR = np.ones(70, dtype=np.float64)
+_ALPHA_FACTOR[[1, 2, 69]] = 0.85
+_ALPHA_FACTOR[[13, 14, 41, 62]] = 1.15
 
 
 def temporal_smooth_ema(X: np.ndarray, target_ids: Sequence[int] = None, alpha: float = 0.7, adaptive: bool = True,
                         alpha_min: float = 0.45, alpha_max: float = 0.92, speed_gain: float = 0.25) -> np.ndarray:
-    """fuse.py:329-412 on a [T, J, 3] array (NaN = missing): EMA with per-joint base alpha
-    (MHR-70 ids: eyes+neck smoother, feet+hands more responsive) and speed-adaptive alpha."""
+    """fuse/fuse.py:329-412 on a [T, J, 3] array (NaN rows = missing joints): an exponential moving average
+    run as a masked scan over time.  State = the previous output row per joint; per step a joint is
+    (observed now) + 2 (has state): 0 -> NaN, 1 -> the observation starts the state, 2 -> the state is held,
+    3 -> a x + (1 - a) y with a = clip(base + speed_gain |x - y|, alpha_min, alpha_max) (adaptive) or alpha."""
     X = np.asarray(X, dtype=np.float64)
     T, J = X.shape[:2]
     if T == 0:
         return X.copy()
-    if target_ids is None:
-        target_ids = list(range(J))
-    core_ids, limb_ids, endpoint_ids = {1, 2, 69}, {5, 6, 7, 8, 9, 10, 11, 12}, {13, 14, 41, 62}
-    alpha_joint = np.full((J,), float(alpha), dtype=np.float64)
     if adaptive:
-        for j, jid in enumerate(target_ids):
-            if jid in core_ids:
-                alpha_joint[j] = alpha * 0.85
-            elif jid in limb_ids:
-                alpha_joint[j] = alpha * 1.00
-            elif jid in endpoint_ids:
-                alpha_joint[j] = alpha * 1.15
-        alpha_joint = np.clip(alpha_joint, alpha_min, alpha_max)
-    Y = np.full_like(X, np.nan)
+        ids = np.arange(J) if target_ids is None else np.asarray(list(target_ids), dtype=np.int64)
+        known = (ids >= 0) & (ids < _ALPHA_FACTOR.size)
+        factor = np.where(known, _ALPHA_FACTOR[np.where(known, ids, 0)], 1.0)
+        base = np.clip(float(alpha) * factor, alpha_min, alpha_max)
+    observed = _row_ok(X)
+    Y = np.empty_like(X)
     Y[0] = X[0]
+    state, has_state = Y[0], observed[0]
     for t in range(1, T):
-        xt, yp = X[t], Y[t - 1]
-        ok_x = np.all(np.isfinite(xt), axis=1)
-        ok_p = np.all(np.isfinite(yp), axis=1)
-        both = ok_x & ok_p
-        if np.any(both):
+        x = X[t]
+        with np.errstate(invalid="ignore"):
             if adaptive:
-                speed = np.linalg.norm(xt[both] - yp[both], axis=1)
-                a = np.clip(alpha_joint[both] + speed_gain * speed, alpha_min, alpha_max)
+                a = np.clip(base + speed_gain * np.linalg.norm(x - state, axis=1), alpha_min, alpha_max)[:, None]
             else:
-                a = np.full((np.count_nonzero(both),), float(alpha), dtype=np.float64)
-            Y[t, both] = a[:, None] * xt[both] + (1.0 - a)[:, None] * yp[both]
-        miss_x = ~ok_x & ok_p
-        Y[t, miss_x] = yp[miss_x]
-        miss_p = ok_x & ~ok_p
-        Y[t, miss_p] = xt[miss_p]
+                a = float(alpha)
+            mix = a * x + (1.0 - a) * state
+        Y[t] = _select_rows(observed[t].astype(np.intp) + 2 * has_state, x, state, mix)
+        state, has_state = Y[t], _row_ok(Y[t])
     return Y
 
 

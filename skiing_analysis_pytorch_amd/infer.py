@@ -84,26 +84,50 @@ def load_and_preprocess_images(image_list: Sequence, mode: str = "crop", device=
     return torch.stack(images)
 
 
+_MISSING = object()
+
+
+def cfg_get(cfg, dotted: str, default=None):
+    """`cfg.a.b` / `cfg["a"]["b"]` / `cfg.a.get("b", default)` of the reference's OmegaConf configs
+    (configs/vggt.yaml), for any mapping- or attribute-style object (omegaconf itself is not needed)."""
+    cur = cfg
+    for key in dotted.split("."):
+        if cur is None:
+            return default
+        nxt = _MISSING
+        if hasattr(cur, "get"):
+            try:
+                nxt = cur.get(key, _MISSING)
+            except TypeError:
+                nxt = _MISSING
+        if nxt is _MISSING:
+            nxt = getattr(cur, key, _MISSING)
+        if nxt is _MISSING:
+            return default
+        cur = nxt
+    return cur
+
+
 class CameraHead:
     """Drop-in for vggt.vggt.infer.CameraHead (the reference-side VGGT wrapper)."""
 
     def __init__(self, cfg=None, out_dir: Optional[Path] = None, model: Optional[VGGT] = None, state_dict=None,
                  prec=PREC_BF16, head_prec=PREC_BF16X3):
-        gpu = 0
-        try:
-            gpu = int(cfg["infer"]["gpu"]) if cfg is not None else 0   # configs/vggt.yaml infer.gpu
-        except (KeyError, TypeError):
-            gpu = 0
+        gpu = int(cfg_get(cfg, "infer.gpu", 0) or 0)   # configs/vggt.yaml infer.gpu
         if not torch.cuda.is_available():
             raise RuntimeError("VGGT needs a GPU.")   # infer.py:49-51
         self.device = f"cuda:{gpu}"
         torch.cuda.set_device(gpu)
         self.outdir = Path(out_dir) if out_dir is not None else None
         # the reference reads these two at the ROOT of the config (infer.py:56-57)
-        self.conf_thres = cfg.get("conf_thres", 50.0) if hasattr(cfg, "get") else 50.0
-        self.prediction_mode = cfg.get("prediction_mode", "All") if hasattr(cfg, "get") else "All"
-        self.vggt = model if model is not None else self.load_vggt_model(self.device, state_dict=state_dict, prec=prec,
-                                                                        head_prec=head_prec)
+        self.conf_thres = cfg_get(cfg, "conf_thres", 50.0)
+        self.prediction_mode = cfg_get(cfg, "prediction_mode", "All")
+        if model is None and state_dict is None:
+            ckpt = cfg_get(cfg, "infer.ckpt_path", None)     # offline stand-in for the URL of infer.py:62-66
+            self.vggt = self.load_vggt_model(self.device, ckpt_path=ckpt, prec=prec, head_prec=head_prec)
+        else:
+            self.vggt = model if model is not None else self.load_vggt_model(self.device, state_dict=state_dict, prec=prec,
+                                                                            head_prec=head_prec)
 
     @staticmethod
     def load_vggt_model(device="cuda", verbose=True, state_dict=None, ckpt_path=None, prec=PREC_BF16,
@@ -145,16 +169,41 @@ class CameraHead:
     def reconstruct_from_frames(self, frame_id: int, imgs: List[torch.Tensor]):
         """infer.py:157-215 -> (extrinsics [S,3,4], intrinsics rescaled to the source resolution
         (list of [3,3]), R [S,3,3], t [S,3], C [S,3], world_points_from_depth)."""
-        H, W = imgs[0].shape[:2]
-        preds, orig_h, orig_w = self.run_vggt(imgs)
-        E, K = preds["extrinsic"], preds["intrinsic"]
-        R, t, C = self.extrinsic_to_RT(E)
-        K_resized = [self.scale_intrinsics(K[i], orig_size=(orig_h, orig_w), new_size=(H, W)) for i in range(len(K))]
-        if self.outdir is not None:
-            d = self.outdir / f"frame_{frame_id:04d}"
-            d.mkdir(parents=True, exist_ok=True)
-            np.savez(d / "predictions.npz", extrinsic=E, intrinsic=K, pose_enc=preds["pose_enc"])
-        return E, K_resized, R, t, C, preds["world_points_from_depth"]
+        return self.reconstruct_batch([frame_id], [imgs])[0]
+
+    @torch.no_grad()
+    def reconstruct_batch(self, frame_ids: Sequence[int], steps: Sequence[List[torch.Tensor]]):
+        """`reconstruct_from_frames` for several independent time steps in ONE model call (B = len(steps),
+        every step S frames of one source size): the steps of a clip are independent
+        (vggt/multi_view_process.py:133), and batching them is what fills the chip.  Returns one
+        reconstruct_from_frames tuple per step; per step `<outdir>/frame_XXXX/predictions.npz` holds the
+        camera arrays of the reference's predictions.npz (vggt/save.py:52-56; the dense maps are returned,
+        not written: the per-frame PNG / GLB / dense dumps are out of scope)."""
+        B, S = len(steps), len(steps[0])
+        H, W = steps[0][0].shape[:2]
+        flat = [im for st in steps for im in st]
+        if len(flat) != B * S:
+            raise ValueError("every time step needs the same number of views")
+
+        def _rgb8(im):
+            return getattr(im, "dtype", None) in (torch.uint8, np.uint8) and getattr(im, "ndim", 0) == 3 and im.shape[2] == 3
+        on_dev = all(_rgb8(im) for im in flat)
+        imgs = load_and_preprocess_images(flat, device=self.device if on_dev else None).to(self.device)
+        oh, ow = imgs.shape[-2:]
+        preds = self.vggt(imgs.view(B, S, 3, oh, ow), want={"camera", "depth"})
+        E, K = geometry.pose_encoding_to_extri_intri(preds["pose_enc"], (oh, ow))
+        wp = torch.stack([geometry.unproject_depth_map_to_point_map(preds["depth"][b], E[b], K[b]) for b in range(B)])
+        En, Kn, wpn, pen = E.cpu().numpy(), K.cpu().numpy(), wp.cpu().numpy(), preds["pose_enc"].cpu().numpy()
+        out = []
+        for b in range(B):
+            R, t, C = self.extrinsic_to_RT(En[b])
+            K_resized = [self.scale_intrinsics(Kn[b, i], orig_size=(oh, ow), new_size=(H, W)) for i in range(S)]
+            if self.outdir is not None:
+                d = self.outdir / f"frame_{int(frame_ids[b]):04d}"
+                d.mkdir(parents=True, exist_ok=True)
+                np.savez(d / "predictions.npz", extrinsic=En[b], intrinsic=Kn[b], pose_enc=pen[b])
+            out.append((En[b], K_resized, R, t, C, wpn[b]))
+        return out
 
 
 def save_camera_info(out_pt_path: Path, all_frame_camera_intrinsics, all_frame_R, all_frame_t, all_frame_C,

@@ -109,8 +109,18 @@ __global__ __launch_bounds__(256) void k64(const unsigned short* A, const unsign
     if (sink && tid == 0) sink[blockIdx.x] = *reinterpret_cast<int*>(smem + 64);
 }
 
+// element counts of the two buffers main() allocates: every case is checked against them before it is
+// launched (an out-of-range case is a GPU memory fault, not a wrong number)
+static const size_t A_ELEMS = (size_t)43968 * 4096, W_ELEMS = (size_t)8192 * 8192;
+static bool in_range(size_t a_need, size_t w_need, const char* what) {
+    if (a_need <= A_ELEMS && w_need <= W_ELEMS) return true;
+    printf("%s: SKIPPED, needs %zu / %zu elements of A / W (have %zu / %zu)\n", what, a_need, w_need, A_ELEMS, W_ELEMS);
+    return false;
+}
+
 template <int DEPTH>
 void run64(const unsigned short* A, const unsigned short* W, int M, int N, int K, int* sink) {
+    if (!in_range(2 * (size_t)M * K, 2 * (size_t)N * K, "run64")) return;
     const int ntm = M / 256, ntn = N / 256;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k64<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     hipEvent_t e0, e1;
@@ -135,6 +145,7 @@ void run64(const unsigned short* A, const unsigned short* W, int M, int N, int K
 
 template <int DEPTH, int BAR, int NW>
 void run(const unsigned short* A, const unsigned short* W, int M, int N, int K, int* sink) {
+    if (!in_range((size_t)M * K, (size_t)N * K, "run")) return;
     const int ntm = M / 256, ntn = N / 256;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k<DEPTH, BAR, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         163840);
@@ -164,11 +175,11 @@ int main() {
     const int M = 8192, N = 8192, K = 8192;
     unsigned short *A, *W;
     int* sink;
-    hipMalloc(&A, (size_t)43968 * 4096 * 2);
-    hipMalloc(&W, (size_t)N * K * 2);
+    hipMalloc(&A, A_ELEMS * 2);
+    hipMalloc(&W, W_ELEMS * 2);
     hipMalloc(&sink, 1 << 20);
-    hipMemset(A, 0, (size_t)43968 * 4096 * 2);
-    hipMemset(W, 0, (size_t)N * K * 2);
+    hipMemset(A, 0, A_ELEMS * 2);
+    hipMemset(W, 0, W_ELEMS * 2);
     run64<2>(A, W, 8192, 2048, 2304, sink);
     run64<4>(A, W, 8192, 2048, 2304, sink);
     run64<6>(A, W, 8192, 2048, 2304, sink);

@@ -319,6 +319,42 @@ def gen_fuse_align():
 GENERATORS["fuse_align"] = gen_fuse_align
 
 
+def gen_geometry():
+    """The geometry post-processing of the path, from the reference's own functions:
+    pose_encoding_to_extri_intri (vggt/vggt/utils/pose_enc.py:62-124), quat_to_mat (utils/rotation.py:14-44),
+    unproject_depth_map_to_point_map (utils/geometry.py:15-117), camera_to_world / qrot
+    (VideoPose3D/common/camera.py:33-34, quaternion.py:10-24), mpjpe (VideoPose3D/common/loss.py:11-17).
+    (vggt/triangulate.py and vggt/multi_view_process.py import cv2 / open3d and cannot be imported here:
+    the DLT and the person-origin helpers stay pinned by the oracle's restatement only.)"""
+    from VideoPose3D.common.camera import camera_to_world
+    from VideoPose3D.common.loss import mpjpe
+    from vggt.vggt.utils.geometry import unproject_depth_map_to_point_map
+    from vggt.vggt.utils.pose_enc import pose_encoding_to_extri_intri
+    from vggt.vggt.utils.rotation import quat_to_mat
+
+    g = torch.Generator().manual_seed(21)
+    pe = torch.randn((2, 5, 9), generator=g) * 0.3
+    pe[..., 3:7] += torch.tensor([0.0, 0.0, 0.0, 1.0])
+    pe[..., 2] += 3.0
+    pe[..., 7:] = 0.6 + 0.5 * torch.rand((2, 5, 2), generator=g)
+    E, K = pose_encoding_to_extri_intri(pe, (294, 518))
+    q = torch.randn((7, 4), generator=g)
+    depth = torch.rand((5, 24, 36, 1), generator=g) * 4 + 0.5
+    wp = unproject_depth_map_to_point_map(depth.numpy(), E[0].numpy(), K[0].numpy())
+    pred = torch.randn((11, 17, 3), generator=g).numpy().astype("float32")
+    rot = np.array([0.1407056450843811, -0.1500701755285263, -0.755240797996521, 0.6223280429840088], dtype="float32")
+    world = camera_to_world(pred.copy(), R=rot, t=0)
+    a, b = torch.randn((4, 9, 17, 3), generator=g), torch.randn((4, 9, 17, 3), generator=g)
+    np.savez_compressed(GOLD / "geometry.npz", pose_enc=pe.numpy(), image_hw=np.array([294, 518]), extrinsic=E.numpy(),
+                        intrinsic=K.numpy(), quat=q.numpy(), rotmat=quat_to_mat(q).numpy(), depth=depth.numpy(),
+                        world_points=wp, cam_pred=pred, cam_rot=rot, cam_world=world, mpjpe_a=a.numpy(), mpjpe_b=b.numpy(),
+                        mpjpe=np.array(float(mpjpe(a, b))))
+    print("wrote geometry.npz")
+
+
+GENERATORS["geometry"] = gen_geometry
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENERATORS)
     for w in which:
