@@ -48,4 +48,13 @@ int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, 
 // VideoPose3D expand-conv im2col: x [B, L, Cin] f32 -> A0 [B*(L-k+1), Kpad] f32 (zero padded)
 int vp3d_im2col_launch(const float* x, float* a0, int B, int L, int Cin, int k, int Kpad, hipStream_t st);
 
+// vp3d_stream.hip: the small-batch weight-streaming path of the TemporalModel (one launch per convolution)
+int vp3d_expand_launch(const float* x, const float* w, int ldw, const float* bias, float* out_f32, void* out_rec, int B, int Lin,
+                       int Cin, int taps, int C, hipStream_t st);
+int vp3d_expand_mfma_launch(const float* x, const void* wfrag, int Kpad, const float* bias, float* out_f32, void* out_rec, int B,
+                            int Lin, int Cin, int taps, int C, hipStream_t st);
+int vp3d_mm_launch(const void* wrec, int Npad, const void* xrec, const float* bias, const float* resid, int resid_L,
+                   int resid_off, float* out_f32, int ldo, void* out_rec, int B, int Lin, int C, int taps, int dil, int N,
+                   int relu, hipStream_t st);
+
 }  // namespace skimi

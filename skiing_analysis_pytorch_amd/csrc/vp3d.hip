@@ -8,7 +8,10 @@
 // (model.py:127,134-135); dropout is identity in eval.  Activations stay fp32 in HBM; the MFMA
 // operands are bf16 (PREC_BF16) or split bf16 hi+lo (PREC_BF16X3, ~fp32 accuracy).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include <map>
 #include <string>
@@ -38,6 +41,13 @@ struct skimi_vp3d {
     std::vector<float*> b_conv;
     void* w_shrink = nullptr;
     float* b_shrink = nullptr;
+    // fp32-accurate mode, small batches (vp3d_stream.hip): every conv's weights pre-split (hi + lo bf16) in the
+    // fragment-major order of that kernel; shrink rows padded to a multiple of 16 with zeros
+    std::vector<void*> w_frag;      // 2 per block
+    void* w_expand_frag = nullptr;  // [C][k0frag], K = taps * Cin zero-padded to a multiple of 32
+    int k0frag = 0;
+    void* w_shrink_frag = nullptr;
+    int shrink_npad = 0;
     std::vector<void*> allocs;
 };
 
@@ -157,6 +167,36 @@ static int fold(skimi_vp3d* h, const std::string& conv, const std::string& bn, i
     return SKIMI_OK;
 }
 
+// Weights [N][K] fp32 -> hi / lo bf16 in the fragment-major order of vp3d_mm_kernel:
+// [Npad / 16][K / 32][hi | lo][kg 0..3][row 0..15][8 elements]; rows N..Npad-1 are zero.
+static unsigned short bf16_rne(float x) {
+    unsigned int u;
+    memcpy(&u, &x, 4);
+    const unsigned int r = u + 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(r >> 16);
+}
+static int upload_frag(skimi_vp3d* h, const std::vector<float>& w, int N, int Npad, int K, void** out) {
+    const size_t S = (size_t)K / 32;
+    std::vector<unsigned short> buf((size_t)Npad * K * 2, 0);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            const float x = w[(size_t)n * K + k];
+            const unsigned short hi = bf16_rne(x);
+            unsigned int hu = (unsigned int)hi << 16;
+            float hf;
+            memcpy(&hf, &hu, 4);
+            const size_t idx = (((size_t)(n >> 4) * S + (size_t)(k >> 5)) * 1024) + (size_t)((((k & 31) >> 3) * 16 + (n & 15)) * 8 + (k & 7));
+            buf[idx] = hi;
+            buf[idx + 512] = bf16_rne(x - hf);
+        }
+    void* d = nullptr;
+    SKIMI_HIP(hipMalloc(&d, buf.size() * 2));
+    h->allocs.push_back(d);
+    SKIMI_HIP(hipMemcpy(d, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+    *out = d;
+    return SKIMI_OK;
+}
+
 // fp32-accurate mode: a block's weight matrix [N, K] also as bf16x3 records, for the LDS-DMA kernel that
 // gemm_dispatch picks once a batch fills the chip with 256-row tiles (gemm_x3dma.hip)
 static int add_records(skimi_vp3d* h, const void* w_f32, int N, int K, bool bf16_mode) {
@@ -179,6 +219,9 @@ int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
     h->allocs.clear();
     h->w_conv.clear();
     h->w_rec.clear();
+    h->w_frag.clear();
+    h->w_shrink_frag = nullptr;
+    h->w_expand_frag = nullptr;
     h->b_conv.clear();
     h->prec = prec;
     const bool bf = prec == SKIMI_PREC_BF16;
@@ -189,6 +232,14 @@ int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
     if ((rc = fold(h, "expand_conv", "expand_bn", C, cin0, h->fw[0], h->k0pad, &w, &b))) return rc;
     if ((rc = upload(h, w, bf, &h->w_expand))) return rc;
     if ((rc = upload(h, b, false, (void**)&h->b_expand))) return rc;
+    h->w_expand_frag = nullptr;
+    if (!bf && C % 32 == 0) {
+        h->k0frag = (int)align_up((size_t)h->fw[0] * cin0, 32);
+        std::vector<float> wp((size_t)C * h->k0frag, 0.f);
+        for (int co = 0; co < C; ++co)
+            for (int k = 0; k < h->fw[0] * cin0; ++k) wp[(size_t)co * h->k0frag + k] = w[(size_t)co * h->k0pad + k];
+        if ((rc = upload_frag(h, wp, C, C, h->k0frag, &h->w_expand_frag))) return rc;
+    }
     for (size_t i = 1; i < h->fw.size(); ++i) {
         char cn[64], bn[64];
         void* dw;
@@ -201,6 +252,11 @@ int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
         h->w_conv.push_back(dw);
         h->b_conv.push_back(db);
         if ((rc = add_records(h, dw, C, h->fw[i] * C, bf))) return rc;
+        if (!bf && C % 32 == 0) {
+            void* fr;
+            if ((rc = upload_frag(h, w, C, C, h->fw[i] * C, &fr))) return rc;
+            h->w_frag.push_back(fr);
+        }
         snprintf(cn, sizeof cn, "layers_conv.%zu", 2 * (i - 1) + 1);
         snprintf(bn, sizeof bn, "layers_bn.%zu", 2 * (i - 1) + 1);
         if ((rc = fold(h, cn, bn, C, C, 1, C, &w, &b))) return rc;
@@ -209,6 +265,11 @@ int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
         h->w_conv.push_back(dw);
         h->b_conv.push_back(db);
         if ((rc = add_records(h, dw, C, C, bf))) return rc;
+        if (!bf && C % 32 == 0) {
+            void* fr;
+            if ((rc = upload_frag(h, w, C, C, C, &fr))) return rc;
+            h->w_frag.push_back(fr);
+        }
     }
     const std::vector<float>*sw, *sb;
     const int nout = h->joints_out * 3;
@@ -216,18 +277,23 @@ int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
     if ((rc = need(h, "shrink.bias", nout, &sb))) return rc;
     if ((rc = upload(h, *sw, bf, &h->w_shrink))) return rc;
     if ((rc = upload(h, *sb, false, (void**)&h->b_shrink))) return rc;
+    if (!bf && C % 32 == 0) {
+        h->shrink_npad = (int)align_up((size_t)nout, 16);
+        if ((rc = upload_frag(h, *sw, nout, h->shrink_npad, C, &h->w_shrink_frag))) return rc;
+    }
     h->finalized = true;
     return SKIMI_OK;
 }
 
 // workspace = A0 [B*L0, k0pad] + three activation buffers [B*L0, C] + split-K slab [B*L0, C]
-//           + two buffers of bf16x3 activation records for the LDS-DMA kernel ([B*L0, C] + 256 each)
+//           + two buffers of pre-split (hi + lo bf16) activations ([B*L0 rounded up to 16, C] + 256 each): records for the
+//             LDS-DMA kernels, fragment-major tiles for the small-batch streaming kernels
 size_t skimi_vp3d_workspace_bytes(const skimi_vp3d* h, int32_t batch, int32_t frames_in) {
     if (!h || batch <= 0 || frames_in < skimi_vp3d_receptive_field(h)) return 0;
     const size_t L0 = (size_t)frames_in - h->fw[0] + 1;
     const size_t rows = (size_t)batch * L0;
     const size_t k0 = align_up((size_t)h->fw[0] * h->joints_in * h->in_features, 8);
-    return align_up(rows * k0 * 4, 256) + 4 * align_up(rows * h->channels * 4, 256) + 2 * align_up(rows * h->channels * 4 + 256, 256);
+    return align_up(rows * k0 * 4, 256) + 4 * align_up(rows * h->channels * 4, 256) + 2 * align_up(align_up(rows, 16) * h->channels * 4 + 256, 256);
 }
 
 int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch, int32_t frames_in,
@@ -256,12 +322,61 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
     float* bufY = (float*)(ws + actb);
     float* bufZ = (float*)(ws + 2 * actb);
     void* slab = ws + 3 * actb;
-    const size_t recb = align_up(rows0 * C * 4 + 256, 256);
+    const size_t recb = align_up(align_up(rows0, 16) * C * 4 + 256, 256);
     char* recX = ws + 4 * actb;     // records of bufX (block input), or split scratch when the chain is off
     char* recY = recX + recb;       // records of the dilated conv's output
     const int wdt = h->prec == SKIMI_PREC_BF16 ? SKIMI_BF16 : SKIMI_F32;
 
     int rc;
+    // Small batches, fp32-accurate mode: the weight-streaming path -- one launch per convolution, no split-K,
+    // no im2col, no slab (vp3d_stream.hip).  SKIMI_VP3D_STREAM=0 forces the generic GEMM chain (A/B timing);
+    // SKIMI_VP3D_STREAM_ROWS moves the switch-over (rows of the first layer; larger batches are MFMA-bound and
+    // run on the LDS-DMA kernels below).
+    {
+        static const int use_stream = getenv("SKIMI_VP3D_STREAM") ? atoi(getenv("SKIMI_VP3D_STREAM")) : 1;
+        static const long max_rows = getenv("SKIMI_VP3D_STREAM_ROWS") ? atol(getenv("SKIMI_VP3D_STREAM_ROWS")) : 2048;
+        const bool ok = use_stream && h->prec == SKIMI_PREC_BF16X3 && h->w_shrink_frag != nullptr && (long)rows0 <= max_rows &&
+                        h->w_frag.size() == 2 * (h->fw.size() - 1);
+        if (ok) {
+            // expand_conv: on the MFMA kernel (bf16x3 like the other layers; SKIMI_VP3D_EXPAND_VALU=1: the exact-fp32 VALU kernel)
+            static const int expand_valu = getenv("SKIMI_VP3D_EXPAND_VALU") ? atoi(getenv("SKIMI_VP3D_EXPAND_VALU")) : 0;
+            if (expand_valu || h->w_expand_frag == nullptr)
+                rc = vp3d_expand_launch(x, (const float*)h->w_expand, h->k0pad, h->b_expand, bufX, recX, batch, frames_in, cin0,
+                                        h->fw[0], C, st);
+            else
+                rc = vp3d_expand_mfma_launch(x, h->w_expand_frag, h->k0frag, h->b_expand, bufX, recX, batch, frames_in, cin0,
+                                             h->fw[0], C, st);
+            if (rc) return rc;
+            int L = L0;
+#ifdef SKIMI_ABLATIONS
+            int mm_left = getenv("SKIMI_VP3D_LAST") ? atoi(getenv("SKIMI_VP3D_LAST")) + 1 : 1 << 30;   // tools/vp3d_phases.py
+#define SKIMI_VP3D_COUNT() if (--mm_left <= 0) return SKIMI_OK
+#else
+#define SKIMI_VP3D_COUNT()
+#endif
+            for (size_t i = 1; i < h->fw.size(); ++i) {
+                const int k = h->fw[i], dil = h->dilation[i];
+                const int Lo = L - (k - 1) * dil;
+                SKIMI_CHECK_ARG(Lo > 0, "skimi_vp3d_forward: sequence too short");
+                // conv k, dilated (+ BN + ReLU): records in, records out
+                if ((rc = vp3d_mm_launch(h->w_frag[2 * (i - 1)], C, recX, h->b_conv[2 * (i - 1)], nullptr, 0, 0, nullptr, C, recY,
+                                         batch, L, C, k, dil, C, 1, st))) return rc;
+                SKIMI_VP3D_COUNT();
+                // conv 1x1 (+ BN + ReLU) + res = x[:, pad+shift : L-pad+shift] (model.py:129-135): the block's
+                // output as fp32 (residual of the next block) and as records (operand of the next layer)
+                if ((rc = vp3d_mm_launch(h->w_frag[2 * (i - 1) + 1], C, recY, h->b_conv[2 * (i - 1) + 1], bufX, L,
+                                         h->pad[i] + h->causal_shift[i], bufZ, C, recX, batch, Lo, C, 1, 1, C, 1, st))) return rc;
+                SKIMI_VP3D_COUNT();
+                float* t = bufX;
+                bufX = bufZ;
+                bufZ = t;
+                L = Lo;
+            }
+            // shrink: 1x1 conv with bias, no activation
+            return vp3d_mm_launch(h->w_shrink_frag, h->shrink_npad, recX, h->b_shrink, nullptr, 0, 0, out, h->joints_out * 3,
+                                  nullptr, batch, L, C, 1, 1, h->joints_out * 3, 0, st);
+        }
+    }
     if ((rc = vp3d_im2col_launch(x, a0, batch, frames_in, cin0, h->fw[0], h->k0pad, st))) return rc;
 
     skimi_gemm_desc d;
