@@ -30,10 +30,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a) {
     const int hd = a.head_dim;
     const int q0 = blockIdx.x * 128 + wave * 32;
 
-    const float* Q = (const float*)a.q + (long)b * a.q_batch + (long)head * a.q_head;
-    const float* K = (const float*)a.k + (long)b * a.k_batch + (long)head * a.k_head;
-    const float* V = (const float*)a.v + (long)b * a.v_batch + (long)head * a.v_head;
-    float* O = (float*)a.out + (long)b * a.o_batch + (long)head * a.o_head;
+    const int go = a.batch_inner > 0 ? b / a.batch_inner : 0, gi = a.batch_inner > 0 ? b - go * a.batch_inner : b;
+    const float* Q = (const float*)a.q + (long)go * a.q_batch2 + (long)gi * a.q_batch + (long)head * a.q_head;
+    const float* K = (const float*)a.k + (long)go * a.k_batch2 + (long)gi * a.k_batch + (long)head * a.k_head;
+    const float* V = (const float*)a.v + (long)go * a.v_batch2 + (long)gi * a.v_batch + (long)head * a.v_head;
+    float* O = (float*)a.out + (long)go * a.o_batch2 + (long)gi * a.o_batch + (long)head * a.o_head;
 
     // Q fragment: lane (q, h) holds Q[q][HDH*h + t], pre-multiplied by the softmax scale
     float qreg[HDH];

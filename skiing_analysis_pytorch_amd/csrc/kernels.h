@@ -28,6 +28,10 @@ struct AttnArgs {
     long q_head, k_head, v_head, o_head;    // stride between heads
     int batch, heads, seq_q, seq_k, head_dim;
     float scale;
+    // optional two-level batch (fp32 kernel only): batch index g = go * batch_inner + gi sits at
+    // go * *_batch2 + gi * *_batch (batch_inner = 0: one level, offset g * *_batch)
+    int batch_inner = 0;
+    long q_batch2 = 0, k_batch2 = 0, v_batch2 = 0, o_batch2 = 0;
 };
 int attention_f32_launch(const AttnArgs& a, hipStream_t st);
 int attention_bf16_launch(const AttnArgs& a, hipStream_t st);

@@ -81,10 +81,12 @@ def test_parity_mode_every_output_at_bench_shape(bench_shape):
     # near 1e-3 px.
     dtr = (out["track"].cpu() - ref["track"]).abs()
     print(f"track px err: median {dtr.median().item():.2e}, p99 {dtr.flatten().kthvalue(int(0.99 * dtr.numel())).values.item():.2e}, max {dtr.max().item():.2e}")
-    # measured on MI355X: median 2.2e-3, p99 4.4e-2, max 0.16 px; vis / conf (sigmoid of the refined features) 8e-3
+    # measured on MI355X: median 2.2e-3, p99 4.4e-2 .. 5.0e-2, max 0.16 px; vis / conf (sigmoid of the refined features):
+    # median ~3e-4, worst element 8e-3 .. 2.3e-2 from run to run (split-K atomics reorder the fp32 sums)
     assert dtr.median().item() < 5e-3 and dtr.max().item() < 0.5
-    assert (out["vis"].cpu() - ref["vis"]).abs().max().item() < 2e-2
-    assert (out["conf"].cpu() - ref["conf"]).abs().max().item() < 2e-2
+    for k in ("vis", "conf"):
+        dv = (out[k].cpu() - ref[k]).abs()
+        assert dv.median().item() < 2e-3 and dv.max().item() < 6e-2, k
     assert torch.allclose(out["track"][:, 0].cpu(), s["queries"], atol=1e-4)
     # the metric's quantity: 3D joints
     e = joints_check.mpjpe(_joints(out, s["kps"]), s["joints_ref"])
