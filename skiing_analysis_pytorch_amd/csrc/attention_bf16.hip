@@ -244,6 +244,10 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
     static const int q64 = getenv("SKIMI_ATTN_Q64") ? atoi(getenv("SKIMI_ATTN_Q64")) : 1;
     if (q64 != 0) {
         attention_q64_dispatch(a, st);
+    } else if (a.q_prescaled) {   // this file's kernel multiplies by scale * log2(e): make that product 1
+        AttnArgs a1 = a;
+        a1.scale = 0.69314718055994530942f;
+        hipLaunchKernelGGL(attn_bf16_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, a1, nqb);
     } else
     switch (dbg) {
 #ifdef SKIMI_ABLATIONS
@@ -264,7 +268,7 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
 }
 
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
-                     hipStream_t st) {
+                     hipStream_t st, int q_prescaled) {
     SKIMI_CHECK_ARG(qkv && out, "skimi_attention: null buffer");
     AttnArgs a;
     const long C = (long)heads * head_dim;
@@ -283,6 +287,7 @@ int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, 
     a.seq_q = a.seq_k = seq;
     a.head_dim = head_dim;
     a.scale = 1.0f / sqrtf((float)head_dim);
+    a.q_prescaled = dtype == SKIMI_F32 ? 0 : q_prescaled;
     if (dtype == SKIMI_F32) return attention_f32_launch(a, st);
     return attention_bf16_launch(a, st);
 }

@@ -16,6 +16,19 @@
 //     partial sums merged once at the end (no ones-matrix MFMAs).
 // Workgroup: 4 waves x 64 queries; K/V tiles of 64 keys double-buffered in LDS by LDS-DMA.
 //
+// Softmax VALU diet (the loop is VALU-bound: profiles/r01_attn_mfma_util.json, MFMA pipes busy 31-36 % of the
+// launch).  Per score the loop used to issue v_fma (scale and subtract the row maximum), v_exp, v_add (row sum),
+// half a v_max3 and half a v_cvt_pk.  The v_fma is gone:
+//   * the softmax scale x log2(e) is folded into q before q's ONE rounding to bf16 (qknorm_rope_launch's q_scale;
+//     q without qk-norm -- the DINOv2 blocks -- is rescaled here when its fragments are loaded);
+//   * the row reference r (a stale row maximum) is subtracted BY THE MATRIX PIPE: S^T starts from one extra
+//     MFMA k-step whose K-side fragment is the unit vector e0 and whose Q-side fragment carries -r, so the
+//     accumulator is already s - r and v_exp2 takes it as it is.  r lives in bf16 (it has to pass through the
+//     operand), which is fine: softmax is invariant to the shift as long as every tile of a row uses the same one;
+//   * r is only moved when a tile's scores exceed it by more than 2^8 (lazy rescale, exact: O, the row sum and
+//     the tile's scores are shifted by the same r' - r), so after the first tiles the rescale branch is dead.
+// 4 extra MFMAs per 64-key tile (36 instead of 32) against 64 fewer VALU instructions per lane.
+//
 // Tried on top of this, no gain (2327-2344 us against 2307-2311 for the bench's global-attention launch):
 // the two query blocks skewed, i.e. block 1's S^T MFMAs issued in one straight-line region with block 0's
 // softmax (last tile peeled) so that they run under its VALU stream.  The loop is VALU- and power-bound
@@ -79,6 +92,15 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[qi][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
+    if (!a.q_prescaled) {   // q straight from a projection (no qk-norm kernel in front): fold scale * log2(e) in here
+        const float c2q = a.scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qi][s][j] = (short)f2bf(bf2f((unsigned short)qf[qi][s][j]) * c2q);
+    }
 
     // K/V staging by LDS-DMA: one wave-instruction lands 8 rows x 128 B linearly, bank swizzles on
     // the per-lane SOURCE chunk (K: chunk ^= (row>>1)&7; V: chunk ^= ((row>>1)&1)<<2), rows past
@@ -110,9 +132,13 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[qi][dt][r] = 0.f;
     float lsum[2] = {0.f, 0.f};   // this lane's partial row sums (its 32 of every 64 keys)
-    float m[2] = {-INFINITY, -INFINITY};
-    const float c2 = a.scale * 1.44269504088896340736f;   // softmax scale folded into exp2
+    float mr[2] = {0.f, 0.f};     // row reference (log2 units, a bf16 value), set from the first tile
+    constexpr float THR = 8.f;    // scores may exceed the reference by 2^8 before it is moved
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the extra k-step: K side = e0 for every key (element k = 0 sits in the lh = 0 half), Q side = -r of the lane's query
+    bf16x8 kone = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (lh == 0) kone[0] = (short)0x3F80;
+    bf16x8 qneg[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
 
     // LDS-DMA double buffer, visibility protocol: a wave's global_load_lds writes land in LDS when ITS vmcnt
     // reaches 0, so every wave waits vmcnt(0) on its own DMA and only then enters the workgroup barrier; after
@@ -140,12 +166,16 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
         }
         __builtin_amdgcn_sched_barrier(0);   // all 8 reads in flight before the first MFMA waits (counted lgkmcnt)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int qi = 0; qi < 2; ++qi)
+                s[qi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, qneg[qi], zero16, 0, 0, 0);   // s = -r
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int qi = 0; qi < 2; ++qi)
-                    s[qi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][ks], qf[qi][ks], ks == 0 ? zero16 : s[qi][t], 0, 0, 0);
+                    s[qi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][ks], qf[qi][ks], s[qi][t], 0, 0, 0);
+        }
 
         // ---- V^T fragments (ds_read_b64_tr_b16 of the row-major [key][d] tile), shared by both blocks ----
         bf16x8 vf[2][2][2];   // [32-key block][16-key step][d tile]
@@ -191,25 +221,34 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
 
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
-            // ---- online softmax: row = query = this lane pair (l31, both halves) ----
+            // ---- online softmax: row = query = this lane pair (l31, both halves); s holds score - r ----
             float mloc = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mloc = __builtin_fmaxf(mloc, s[qi][t][r]);
             mloc = xhalf_max(mloc);
-            const float mnew = __builtin_fmaxf(m[qi], mloc);
-            const float nmb = -(mnew * c2);
-            // exact skip of the O / l rescale when no lane's running max moved
-            if (!__all(mnew == m[qi])) {
-                const float alpha = __builtin_amdgcn_exp2f((m[qi] - mnew) * c2);
+            // move the reference: always on the first tile (r := the tile's maximum), later only when some row's
+            // scores run more than 2^THR above it.  Exact: O, the row sum and this tile's scores shift together.
+            if (kt == 0 || __any(mloc > THR)) {
+                const float want = mr[qi] + (kt == 0 ? mloc : __builtin_fmaxf(mloc, 0.f));
+                const float mnew = bf2f(f2bf(want));          // the reference has to be a bf16 value
+                const float dlt = mnew - mr[qi];              // exact in fp32
+                if (kt != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-dlt);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o[qi][0][r] *= alpha;
-                    o[qi][1][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) {
+                        o[qi][0][r] *= alpha;
+                        o[qi][1][r] *= alpha;
+                    }
+                    lsum[qi] *= alpha;
                 }
-                lsum[qi] *= alpha;
-                m[qi] = mnew;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[qi][t][r] -= dlt;
+                mr[qi] = mnew;
+                qneg[qi][0] = lh == 0 ? (short)f2bf(-mnew) : (short)0;
             }
             // scalar VALU on purpose: packed-fp32 (VOP3P) ops do not co-issue with MFMAs (build.py)
             float l0 = 0.f, l1 = 0.f;
@@ -217,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    float v0 = __builtin_fmaf(s[qi][t][r], c2, nmb), v1 = __builtin_fmaf(s[qi][t][r + 1], c2, nmb);
+                    float v0 = s[qi][t][r], v1 = s[qi][t][r + 1];
                     if (!(dbg & 2)) {
                         v0 = __builtin_amdgcn_exp2f(v0);
                         v1 = __builtin_amdgcn_exp2f(v1);

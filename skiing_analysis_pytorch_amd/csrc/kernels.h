@@ -15,7 +15,9 @@ int layernorm_launch(const float* x, const float* x2, int64_t ldx, int64_t rows,
 int qknorm_rope_launch(void* qkv, int dtype, int64_t tokens, int heads, const float* qn_w,
                        const float* qn_b, const float* kn_w, const float* kn_b, float eps,
                        const int32_t* pos, const float* rope_cos, const float* rope_sin, int rope_npos,
-                       hipStream_t st);
+                       hipStream_t st, float q_scale = 1.f, int* q_scaled = nullptr);
+// q_scale / q_scaled: the bf16 fast path can fold the softmax scale (x log2 e) into q BEFORE its one rounding
+// to bf16 (attention_q64.hip then takes exp2 of the raw MFMA accumulator); *q_scaled says whether it did.
 
 // general attention: q rows [batch, seq_q], k/v rows [batch, seq_k]; element strides
 struct AttnArgs {
@@ -32,6 +34,7 @@ struct AttnArgs {
     // go * *_batch2 + gi * *_batch (batch_inner = 0: one level, offset g * *_batch)
     int batch_inner = 0;
     long q_batch2 = 0, k_batch2 = 0, v_batch2 = 0, o_batch2 = 0;
+    int q_prescaled = 0;   // bf16 kernels: q already carries scale * log2(e) (qknorm_rope_launch's q_scale)
 };
 int attention_f32_launch(const AttnArgs& a, hipStream_t st);
 int attention_bf16_launch(const AttnArgs& a, hipStream_t st);
@@ -47,7 +50,7 @@ int conv_direct_n32_launch(const unsigned short* in_hi, const unsigned short* in
                            long px_stride = 0);   // 0: separate planes [.., C]; 2C: pixel records [hi C | lo C]
 void attention_q64_dispatch(const AttnArgs& a, hipStream_t st);    // attention_q64.hip: 64 queries per wave
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
-                     hipStream_t st);
+                     hipStream_t st, int q_prescaled = 0);
 
 // VideoPose3D expand-conv im2col: x [B, L, Cin] f32 -> A0 [B*(L-k+1), Kpad] f32 (zero padded)
 int vp3d_im2col_launch(const float* x, float* a0, int B, int L, int Cin, int k, int Kpad, hipStream_t st);

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bf16_kernel(unsigned short* _
                                                                const float* __restrict__ kn_b, float eps,
                                                                const int* __restrict__ pos,
                                                                const float* __restrict__ rcos,
-                                                               const float* __restrict__ rsin, int npos) {
+                                                               const float* __restrict__ rsin, int npos, float q_scale) {
     extern __shared__ __attribute__((aligned(16))) float tab[];   // [2][npos][16]
     for (int i = threadIdx.x; i < npos * 16; i += 256) {
         tab[i] = rcos[i];
@@ -391,7 +391,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_bf16_kernel(unsigned short* _
             for (int j = 0; j < 8; ++j) {
                 const float other = dpp_xor2(t[j]);   // feature d +- 16 lives two lanes away
                 const float rot = lower ? -other : other;
-                outv[z][j] = (short)f2bf(t[j] * ct[j] + rot * st[j]);
+                const float r = t[j] * ct[j] + rot * st[j];
+                outv[z][j] = (short)f2bf(z == 0 ? r * q_scale : r);   // q: softmax scale folded in before the one rounding
             }
         }
         if (live) {
@@ -403,15 +404,18 @@ __global__ __launch_bounds__(256) void qknorm_rope_bf16_kernel(unsigned short* _
 
 int qknorm_rope_launch(void* qkv, int dtype, int64_t tokens, int heads, const float* qn_w, const float* qn_b,
                        const float* kn_w, const float* kn_b, float eps, const int32_t* pos,
-                       const float* rope_cos, const float* rope_sin, int rope_npos, hipStream_t st) {
+                       const float* rope_cos, const float* rope_sin, int rope_npos, hipStream_t st, float q_scale,
+                       int* q_scaled) {
     SKIMI_CHECK_ARG(qkv && tokens > 0 && heads > 0, "skimi_qknorm_rope: bad arguments");
+    if (q_scaled) *q_scaled = 0;
     SKIMI_CHECK_ARG(pos == nullptr || (rope_cos && rope_sin && rope_npos > 0), "skimi_qknorm_rope: pos without tables");
     if (((uintptr_t)qkv & 15) == 0 && dtype == SKIMI_BF16 && qn_w && kn_w && pos && rope_npos * 128 <= 48 * 1024) {
         const long total = tokens * heads;
         const unsigned blocks = (unsigned)std::min<long>(cdiv(total, 32), 256 * 8);
         hipLaunchKernelGGL(qknorm_rope_bf16_kernel, dim3(blocks), dim3(256), (size_t)rope_npos * 128, st,
                            (unsigned short*)qkv, (long)tokens, heads, qn_w, qn_b, kn_w, kn_b, eps, pos, rope_cos, rope_sin,
-                           rope_npos);
+                           rope_npos, q_scaled ? q_scale : 1.f);
+        if (q_scaled) *q_scaled = 1;
         SKIMI_LAUNCH_CHECK();
         return SKIMI_OK;
     }

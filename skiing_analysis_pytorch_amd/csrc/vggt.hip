@@ -412,11 +412,16 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
         auto d = c.desc(w.qkv, b.xn, adt, C, M, b.qkv, adt, 3 * C);
         c.gemm(d);
     }
+    int q_scaled = 0;
     if (!c.rc && !c.dry() && (w.qn_w || rope)) {
+        // bf16 mode: the softmax scale (x log2 e) rides in q's one rounding to bf16, the attention kernel then
+        // exponentiates the raw accumulator
+        const float q_scale = (1.0f / sqrtf((float)(C / heads))) * 1.44269504088896340736f;
         c.rc = qknorm_rope_launch(b.qkv, adt, M, heads, w.qn_w, w.qn_b, w.kn_w, w.kn_b, 1e-5f, rope ? c.tabs->pos : nullptr,
-                                  c.tabs->rope_cos, c.tabs->rope_sin, c.tabs->rope_npos, c.st);
+                                  c.tabs->rope_cos, c.tabs->rope_sin, c.tabs->rope_npos, c.st, q_scale,
+                                  adt == SKIMI_BF16 && C / heads == 64 ? &q_scaled : nullptr);
     }
-    if (!c.rc && !c.dry()) c.rc = attention_launch(b.qkv, b.ao, adt, batch, seq, heads, C / heads, c.st);
+    if (!c.rc && !c.dry()) c.rc = attention_launch(b.qkv, b.ao, adt, batch, seq, heads, C / heads, c.st, q_scaled);
     {
         auto d = c.desc(w.proj, b.ao, adt, C, M, x, SKIMI_F32, C);
         d.gamma = w.ls1; d.resid = x; d.ldr = C;
