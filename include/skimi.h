@@ -53,6 +53,11 @@ extern "C" {
  *                       parity bar against the fp32 CPU reference */
 #define SKIMI_PREC_BF16 0
 #define SKIMI_PREC_BF16X3 1
+/* SKIMI_PREC_FP8 (skimi_vggt_config.prec only; BASELINE config 5): as SKIMI_PREC_BF16, but the qkv / fc1 / fc2
+ * Linear layers of every DINOv2 / frame / global block (vggt/vggt/layers/block.py:77-98, mlp.py:34-40,
+ * attention.py:50-72) run on the MXFP8 MFMA (skimi_gemm_fp8): weights quantised once at finalize, activations
+ * per call (skimi_quant_mx); attention, LayerNorm, residual stream and the heads are unchanged. */
+#define SKIMI_PREC_FP8 2
 
 /* activation in the GEMM epilogue */
 #define SKIMI_ACT_NONE 0
@@ -164,6 +169,20 @@ int skimi_split_planes(const float* x, int64_t ld, int64_t rows, int32_t C, void
 int skimi_split_records(const float* x, int64_t ld, int64_t rows, int32_t C, void* records, void* stream);
 
 int skimi_gemm(const skimi_gemm_desc* d, void* stream);
+
+/* OCP microscaling FP8 (MXFP8) operands of skimi_gemm_fp8: x [rows, K] (bf16 or fp32, row stride ldx elements,
+ * 16-byte aligned rows) -> payload [rows][Kp] e4m3 bytes (Kp = K rounded up to 128, tail zero) and scales
+ * [rows][Kp / 32] E8M0 bytes (value 2^(byte - 127); per 32-element block the smallest power of two with
+ * amax / scale <= 448, so no element clips; 0 for an all-zero block). */
+int skimi_quant_mx(const void* x, int32_t dtype, int64_t ldx, int64_t rows, int32_t K, void* payload, void* scales,
+                   void* stream);
+/* out[m][n] = epilogue(sum_k A[m][k] W[n][k]) on v_mfma_scale_f32_32x32x64_f8f6f4, both operands as written by
+ * skimi_quant_mx (nn.Linear layout for W: [N, K]).  Epilogue: + bias[n] (or NULL); act = SKIMI_ACT_NONE or
+ * SKIMI_ACT_GELU; or, with gamma != NULL, gamma[n] * (. + bias[n]) + resid[m][n] (fp32, row stride ldr; may alias
+ * out: block.py:77-98's LayerScale + residual).  out fp32 or bf16, row stride ldo; N, ldo, ldr multiples of 4. */
+int skimi_gemm_fp8(const void* A, const void* A_scales, const void* W, const void* W_scales, int32_t M, int32_t N,
+                   int32_t K, const float* bias, int32_t act, const float* gamma, const float* resid, int64_t ldr,
+                   void* out, int32_t out_dtype, int64_t ldo, void* stream);
 
 /* Direct 3x3 convolution (stride 1, pad 1) of a channels-last image to 32 output channels in the
  * fp32-accurate mode: the last conv of the DPT heads at full resolution

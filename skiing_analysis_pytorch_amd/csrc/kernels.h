@@ -55,6 +55,11 @@ int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, 
 // VideoPose3D expand-conv im2col: x [B, L, Cin] f32 -> A0 [B*(L-k+1), Kpad] f32 (zero padded)
 int vp3d_im2col_launch(const float* x, float* a0, int B, int L, int Cin, int k, int Kpad, hipStream_t st);
 
+// gemm_fp8.hip: MXFP8 operands (e4m3 + E8M0 per 32 K) and the scaled-MFMA contraction
+int quant_mx_launch(const void* x, int dtype, long ldx, long rows, int K, void* q, void* scales, hipStream_t st);
+int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws, int M, int N, int K, const float* bias, int act,
+                    const float* gamma, const float* resid, long ldr, void* out, int out_dtype, long ldo, hipStream_t st);
+
 // vp3d_stream.hip: the small-batch weight-streaming path of the TemporalModel (one launch per convolution)
 int vp3d_expand_launch(const float* x, const float* w, int ldw, const float* bias, float* out_f32, void* out_rec, int B, int Lin,
                        int Cin, int taps, int C, hipStream_t st);

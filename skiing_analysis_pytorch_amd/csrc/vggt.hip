@@ -42,6 +42,8 @@ struct Lin {              // out = A . W^T (+ b)
     int N = 0, K = 0;     // K as seen by the GEMM (padded)
     int prec = SKIMI_PREC_BF16X3;
     void* w_split = nullptr;   // BF16X3 only: bf16 [hi 32 | lo 32] records for the LDS-DMA kernel (wide 3x3 convs)
+    void* wq = nullptr;        // SKIMI_PREC_FP8 blocks: the same matrix as MXFP8 payload [N][Kp] + scales [N][Kp / 32]
+    void* wq_scales = nullptr;
 };
 struct LNw { float* g = nullptr; float* b = nullptr; };
 struct BlockW {
@@ -269,14 +271,29 @@ struct Packer {
         if (L.b) rc = rc ? rc : tile_vec_launch(bsrc, L.b, C, s * s, st);
         return L;
     }
-    BlockW block(const std::string& p, int C, int hidden, bool qk_norm, int hd, int prec) {
+    // MXFP8 copy of a packed Linear (from the staged fp32 weights: one rounding)
+    void add_fp8(Lin& L, const std::string& p, int N, int K) {
+        if (rc) return;
+        const size_t Kp = align_up((size_t)K, 128);
+        L.wq = dmalloc((size_t)N * Kp);
+        L.wq_scales = dmalloc((size_t)N * (Kp / 32));
+        if (L.wq && L.wq_scales) rc = quant_mx_launch(raw(p + ".weight", (int64_t)N * K), SKIMI_F32, K, N, K, L.wq, L.wq_scales, st);
+    }
+    BlockW block(const std::string& p, int C, int hidden, bool qk_norm, int hd, int prec_in) {
         BlockW b;
+        const bool fp8 = prec_in == SKIMI_PREC_FP8 && C % 32 == 0 && hidden % 32 == 0;
+        const int prec = prec_in == SKIMI_PREC_FP8 ? SKIMI_PREC_BF16 : prec_in;
         b.n1 = ln(p + ".norm1", C);
         b.n2 = ln(p + ".norm2", C);
         b.qkv = linear(p + ".attn.qkv", 3 * C, C, prec);
         b.proj = linear(p + ".attn.proj", C, C, prec);
         b.fc1 = linear(p + ".mlp.fc1", hidden, C, prec);
         b.fc2 = linear(p + ".mlp.fc2", C, hidden, prec);
+        if (fp8) {
+            add_fp8(b.qkv, p + ".attn.qkv", 3 * C, C);
+            add_fp8(b.fc1, p + ".mlp.fc1", hidden, C);
+            add_fp8(b.fc2, p + ".mlp.fc2", C, hidden);
+        }
         b.ls1 = keep(p + ".ls1.gamma", C);
         b.ls2 = keep(p + ".ls2.gamma", C);
         if (qk_norm) {
@@ -349,7 +366,7 @@ struct Ctx {
     size_t slab_bytes = 0;
 
     bool dry() const { return ar.dry; }
-    static int act_dt(int prec) { return prec == SKIMI_PREC_BF16 ? SKIMI_BF16 : SKIMI_F32; }
+    static int act_dt(int prec) { return prec == SKIMI_PREC_BF16X3 ? SKIMI_F32 : SKIMI_BF16; }   // BF16 and FP8 modes: bf16 activations
     static size_t esz(int dt) { return dt == SKIMI_F32 ? 4 : 2; }
 
     void gemm(skimi_gemm_desc& d) {
@@ -399,7 +416,7 @@ struct Ctx {
 
 // one pre-LN transformer block on the fp32 residual stream x [batch*seq, C]
 // (vggt/vggt/layers/block.py:77-98 + attention.py:50-72), scratch buffers supplied by the caller
-struct BlockBufs { void* xn; void* qkv; void* ao; void* hid; };
+struct BlockBufs { void* xn; void* qkv; void* ao; void* hid; void* q8 = nullptr; void* q8s = nullptr; };   // q8: MXFP8 scratch [M][4C] + scales
 
 void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int heads, float eps, bool rope,
                const BlockBufs& b) {
@@ -407,8 +424,14 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
     const int prec = w.qkv.prec;
     const int adt = Ctx::act_dt(prec);
     const int hidden = w.fc1.N;
+    const bool fp8 = w.qkv.wq != nullptr && b.q8 != nullptr;   // SKIMI_PREC_FP8: qkv, fc1, fc2 on the MXFP8 MFMA
     c.ln(x, nullptr, C, M, C, w.n1, eps, b.xn, adt);
-    {
+    if (fp8) {
+        if (!c.rc && !c.dry()) c.rc = quant_mx_launch(b.xn, SKIMI_BF16, C, M, C, b.q8, b.q8s, c.st);
+        if (!c.rc && !c.dry())
+            c.rc = gemm_fp8_launch(b.q8, b.q8s, w.qkv.wq, w.qkv.wq_scales, M, 3 * C, C, w.qkv.b, SKIMI_ACT_NONE, nullptr, nullptr, 0,
+                                   b.qkv, SKIMI_BF16, 3 * C, c.st);
+    } else {
         auto d = c.desc(w.qkv, b.xn, adt, C, M, b.qkv, adt, 3 * C);
         c.gemm(d);
     }
@@ -428,6 +451,17 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
         c.gemm(d);
     }
     c.ln(x, nullptr, C, M, C, w.n2, eps, b.xn, adt);
+    if (fp8) {
+        if (!c.rc && !c.dry()) c.rc = quant_mx_launch(b.xn, SKIMI_BF16, C, M, C, b.q8, b.q8s, c.st);
+        if (!c.rc && !c.dry())
+            c.rc = gemm_fp8_launch(b.q8, b.q8s, w.fc1.wq, w.fc1.wq_scales, M, hidden, C, w.fc1.b, SKIMI_ACT_GELU, nullptr, nullptr, 0,
+                                   b.hid, SKIMI_BF16, hidden, c.st);
+        if (!c.rc && !c.dry()) c.rc = quant_mx_launch(b.hid, SKIMI_BF16, hidden, M, hidden, b.q8, b.q8s, c.st);
+        if (!c.rc && !c.dry())
+            c.rc = gemm_fp8_launch(b.q8, b.q8s, w.fc2.wq, w.fc2.wq_scales, M, C, hidden, w.fc2.b, SKIMI_ACT_NONE, w.ls2, x, C, x,
+                                   SKIMI_F32, C, c.st);
+        return;
+    }
     {
         auto d = c.desc(w.fc1, b.xn, adt, C, M, b.hid, adt, hidden);
         d.act = SKIMI_ACT_GELU;
@@ -866,6 +900,11 @@ int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query,
         bb.qkv = c.ar.alloc((size_t)M * 3 * C * es);
         bb.ao = c.ar.alloc((size_t)M * C * es);
         bb.hid = c.ar.alloc((size_t)M * 4 * C * es);
+        if (cfg.prec == SKIMI_PREC_FP8) {   // MXFP8 scratch of the widest quantised activation (the MLP hidden)
+            const size_t kp = align_up((size_t)4 * C, 128);
+            bb.q8 = c.ar.alloc((size_t)M * kp);
+            bb.q8s = c.ar.alloc((size_t)M * (kp / 32));
+        }
         // ---- patch embed (aggregator.py:195-208) ----
         void* pa = c.ar.alloc((size_t)F * np * h->patch_kp * es);
         if (!c.rc && !c.dry()) c.rc = patch_gather_launch(images, pa, adt, F, H, W, p, h->patch_kp, c.st);
@@ -1032,7 +1071,7 @@ int skimi_vggt_finalize(skimi_vggt* h) {
     const int kraw = 3 * p * p;
     // ---- patch embed ----
     const std::string pe = cfg.use_dino ? A + ".patch_embed.patch_embed.proj" : A + ".patch_embed.proj";
-    h->patch_proj = pk.linear(pe, C, kraw, cfg.prec);
+    h->patch_proj = pk.linear(pe, C, kraw, cfg.prec == SKIMI_PREC_FP8 ? SKIMI_PREC_BF16 : cfg.prec);   // FP8 mode: only the block Linears are MXFP8
     h->patch_kp = h->patch_proj.K;
     if (cfg.use_dino) {
         const std::string d = A + ".patch_embed";

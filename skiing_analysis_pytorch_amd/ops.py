@@ -178,3 +178,28 @@ def split_planes(x):
     check(lib().skimi_split_planes(ptr(x), x.stride(0), rows, Cc, ptr(out[0]), ptr(out[1]), _lib.current_stream()),
           "skimi_split_planes")
     return out
+
+
+def quant_mx(x: torch.Tensor):
+    """x [rows, K] (f32 | bf16, device) -> (payload uint8 [rows, Kp], scales uint8 [rows, Kp / 32]): the MXFP8
+    operand form of `gemm_fp8` (e4m3 elements, one E8M0 scale per 32 elements, Kp = K rounded up to 128)."""
+    _require_cuda(x)
+    x = x.contiguous()
+    rows, K = x.shape
+    Kp = (K + 127) // 128 * 128
+    q = torch.empty((rows, Kp), dtype=torch.uint8, device=x.device)
+    s = torch.empty((rows, Kp // 32), dtype=torch.uint8, device=x.device)
+    check(lib().skimi_quant_mx(ptr(x), _dt(x), x.stride(0), rows, K, ptr(q), ptr(s), _lib.current_stream()), "skimi_quant_mx")
+    return q, s
+
+
+def gemm_fp8(a_q, a_s, w_q, w_s, K, *, bias=None, act=ACT_NONE, gamma=None, resid=None, out=None, out_dtype=torch.float32):
+    """out[m][n] = epilogue(sum_k A[m][k] W[n][k]) on the MXFP8 MFMA; operands from `quant_mx`."""
+    _require_cuda(a_q, a_s, w_q, w_s, bias, gamma, resid, out)
+    M, N = a_q.shape[0], w_q.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a_q.device)
+    check(lib().skimi_gemm_fp8(ptr(a_q), ptr(a_s), ptr(w_q), ptr(w_s), M, N, K, ptr(bias), act, ptr(gamma), ptr(resid),
+                               resid.stride(0) if resid is not None else 0, ptr(out), _dt(out), out.stride(0),
+                               _lib.current_stream()), "skimi_gemm_fp8")
+    return out

@@ -228,3 +228,33 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(rf["achieved"] - rf["flops_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e12) < 1e-6 * rf["achieved"]
     cb = line["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+def test_mxfp8_oracle_known_answers():
+    """The oracle's e4m3fn / E8M0 arithmetic against the formats' published constants (OCP OFP8 rev 1.0: bias 7, max
+    448 = 0x7E, min normal 2^-6 = 0x08, min subnormal 2^-9 = 0x01, 0x7F NaN; MX v1.0: E8M0 value 2^(byte - 127))."""
+    from oracle import mxfp8_oracle as mx
+
+    t = mx.e4m3_decode_table()
+    assert t[0x7E] == 448.0 and t[0x08] == 2.0 ** -6 and t[0x01] == 2.0 ** -9 and t[0x38] == 1.0 and t[0xB8] == -1.0
+    assert np.isnan(t[0x7F]) and np.isnan(t[0xFF]) and t[0x00] == 0.0
+    assert np.all(np.diff(t[:127]) > 0)                              # codes 0 .. 126 are increasing
+    enc = mx.e4m3_encode(np.array([0.0, 1.0, -1.0, 448.0, 1000.0, 2.0 ** -9, 2.0 ** -10, 1.0625, 1.1875, 17.0, 19.0]))
+    #   ties to even: 2^-10 is halfway 0 / 0x01 -> 0; 1.0625 halfway 1.0 (0x38) / 1.125 (0x39) -> 0x38; 1.1875 -> 0x3A
+    #   17 halfway 16 (0x58) / 18 (0x59) -> 0x58; 19 halfway 18 / 20 (0x5A) -> 0x5A
+    assert enc.tolist() == [0x00, 0x38, 0xB8, 0x7E, 0x7E, 0x01, 0x00, 0x38, 0x3A, 0x58, 0x5A]
+    assert np.array_equal(mx.e4m3_encode(t[:127]), np.arange(127, dtype=np.uint8))      # decode / encode round trip
+    # block scale: smallest power of two with amax / scale <= 448
+    x = np.zeros((3, 64), dtype=np.float32)
+    x[0, 0] = 448.0; x[0, 40] = 449.0; x[1, 5] = 1.0; x[2, :] = 0.0
+    q, s = mx.mx_quantize(x)
+    assert q.shape == (3, 128) and s.shape == (3, 4)
+    assert s[0, 0] == 127 and s[0, 1] == 128 and s[1, 0] == 127 - 8 and s[2, 0] == 0 and s[0, 3] == 0   # 1/256 <= 448 ... 2^-8
+    d = mx.mx_dequantize(q, s)
+    assert d[0, 0] == 448.0 and d[1, 5] == 1.0 and abs(d[0, 40] - 449.0) <= 449.0 * 2.0 ** -4
+    # quantisation error bound of a block: half a step of the largest binade, 2^-4 relative to amax
+    rng = np.random.default_rng(0)
+    y = rng.normal(size=(5, 96)).astype(np.float32)
+    q, s = mx.mx_quantize(y)
+    err = np.abs(mx.mx_dequantize(q, s)[:, :96] - y).reshape(5, 3, 32).max(axis=2)
+    assert np.all(err <= np.abs(y).reshape(5, 3, 32).max(axis=2) * 2.0 ** -4)
