@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--no-vp3d", action="store_true", help="skip the VideoPose3D lifter leg (profiling runs)")
     ap.add_argument("--no-track", action="store_true", help="leave the track head out of the step (39.6 instead of 40.6 TFLOP)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the timing of the fp32-accurate (bf16x3) mode")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the MXFP8 leg (BASELINE config 5)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -111,10 +112,12 @@ def main():
               torch.rand((B, S_VIEWS, 17, 2), generator=g, device=dev, dtype=torch.float32) * (IMG - 40) + 20)
              for _ in range(NS - 1)]
 
+    active = {"model": model}    # the fp8 leg re-runs the same step on the SKIMI_PREC_FP8 model
+
     def step_on(images_k, kps_k):
         # VGGT forward (all four heads, as `self.vggt(imgs, query_points)` computes them) -> cameras -> DLT
         # triangulation of the joints over the 8 views -> [B, 17, 3]
-        out = model(images_k, query_points=kps_k[:, 0].contiguous() if track else None, want=want)
+        out = active["model"](images_k, query_points=kps_k[:, 0].contiguous() if track else None, want=want)
         E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (IMG, IMG))
         out["joints3d_local"] = geometry.triangulate_joints(K, E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous(), kps_k)
         return out
@@ -238,11 +241,38 @@ def main():
             a1 = fl.value / (ms.value * 1e-3) / 1e12
             line["roofline"]["one_stream"] = {"achieved": a1, "frac": a1 / PEAK_BF16_TFLOPS,
                                               "avg_launch_us": ms.value * 1e3 / n.value, "launches": int(n.value)}
+    if rank == 0 and world == 1 and not args.no_fp8:
+        # BASELINE config 5: the same step with the qkv / fc1 / fc2 Linears of every block on the MXFP8 MFMA
+        # (SKIMI_PREC_FP8); not part of `value`.  Same inputs, same step code, its own timed region.
+        from skiing_analysis_pytorch_amd._lib import PREC_FP8
+        m8 = vggt.VGGT(config=cfg, prec=PREC_FP8, head_prec=PREC_BF16X3)
+        m8.load_state_dict(W.make_vggt_state_dict(cfg, seed=0, device=dev))
+        torch.cuda.empty_cache()
+        active["model"] = m8
+        step()
+        step() if NS == 1 else step_multi(NS)
+        torch.cuda.synchronize()
+        t8 = time.perf_counter()
+        n8 = max(2, args.steps // 2)
+        for _ in range(n8):
+            out8 = step() if NS == 1 else step_multi(NS)
+        torch.cuda.synchronize()
+        dt8 = (time.perf_counter() - t8) / n8
+        assert torch.isfinite(out8["pose_enc"]).all()
+        line["fp8"] = {"value": B * NS / dt8, "unit": "frames/s", "ms_per_step": dt8 * 1e3, "steps": n8,
+                       "mode": "SKIMI_PREC_FP8: MXFP8 (e4m3 + E8M0 per 32 K) qkv / fc1 / fc2 of the 72 blocks on "
+                               "v_mfma_scale_f32_32x32x64_f8f6f4, activations quantised per call; attention, proj, "
+                               "LayerNorm, residual stream as the bf16 mode; heads bf16x3",
+                       "pose_enc_max_abs_diff_vs_bf16_mode": (out8["pose_enc"] - out["pose_enc"]).abs().max().item()}
+        active["model"] = model
+        fp8_model = m8
+    else:
+        fp8_model = None
     if rank == 0 and world == 1 and not args.no_vp3d:
         line["vp3d"] = vp3d_leg(dev, cpu=not args.no_cpu_baseline)
     if rank == 0 and cpu_sd is not None:
         line["cpu_baseline"], line["mpjpe_vs_cpu_oracle"], line["parity_mode"] = cpu_baseline(
-            cpu_sd, cfg, model, dev, track, not args.no_parity_mode)
+            cpu_sd, cfg, model, dev, track, not args.no_parity_mode, fp8_model)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_dist:
@@ -384,7 +414,7 @@ def pmc_traffic(time_steps):
     return d["hbm_bytes_per_launch"]
 
 
-def cpu_baseline(cpu_sd, cfg, model, dev, track, parity_mode):
+def cpu_baseline(cpu_sd, cfg, model, dev, track, parity_mode, fp8_model=None):
     """The oracle (fp32 CPU restatement of the reference, oracle/vggt_oracle.py) MEASURED on one full
     8-view 518x518 step of the benchmarked workload (all heads) on this host's cores -- the bounded sample:
     about a minute of CPU work.  The same step then goes through the benchmarked HIP model (bf16
@@ -432,6 +462,13 @@ def cpu_baseline(cpu_sd, cfg, model, dev, track, parity_mode):
     if track:
         parity["bf16_bench_mode"]["track_px_err_median"] = (got["track"].cpu() - ref["track"]).abs().median().item()
     parity["bf16_bench_mode"]["within_bar"] = parity["bf16_bench_mode"]["mpjpe"] <= 1e-3
+    if fp8_model is not None:    # config 5's parity, reported separately
+        got8, j8 = joints_of(fp8_model)
+        parity["fp8_mode"] = {"mpjpe": joints_check.mpjpe(j8, joints_ref),
+                              "pose_enc_max_abs_err": (got8["pose_enc"].cpu() - ref["pose_enc"]).abs().max().item(),
+                              "depth_rel_err_median": ((got8["depth"].cpu() - ref["depth"]).abs() / (ref["depth"].abs() + 1.0)).median().item(),
+                              "within_bar": False}
+        parity["fp8_mode"]["within_bar"] = parity["fp8_mode"]["mpjpe"] <= 1e-3
     pm = None
     if parity_mode:
         m3 = vggt.VGGT(config=cfg, prec=PREC_BF16X3, head_prec=PREC_BF16X3)

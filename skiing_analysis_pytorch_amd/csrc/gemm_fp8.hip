@@ -12,9 +12,9 @@
 //           amax / scale <= 448 (no element clips)
 // quant_mx_kernel produces that pair from bf16 / fp32 rows (weights once at finalize, activations per call).
 //
-// gemm_fp8_kernel: 128 x 128 output tile, 4 waves (2 x 2, each 64 x 64 = 2 x 2 MFMA tiles), K-tile 128 bytes,
+// gemm_fp8_kernel: 256 x 256 (or, for small shapes, 128 x 128) output tile, 4 waves as 2 x 2, K-tile 128 bytes,
 // both operand tiles double-buffered in LDS by LDS-DMA (global_load_lds_dwordx4, bank swizzle on the source
-// chunk as in the other kernels), 2 workgroups per CU.  The product is computed swapped (W as the MFMA's A
+// chunk as in the other kernels).  The product is computed swapped (W as the MFMA's A
 // operand): a lane then owns 4 consecutive output columns of one token row, i.e. 16-byte fp32 / 8-byte bf16
 // stores.  The E8M0 dword of a row's K-tile is read straight from global memory (L2) one tile ahead; the byte
 // for k-step ks and lane half lh (= scale block 2 ks + lh of the tile) is picked by a per-lane shift (8 lh) plus
@@ -136,11 +136,14 @@ struct Fp8Args {
     int ntm, ntn;
 };
 
-// EPI 0: bias; 1: bias + GELU; 2: bias, * gamma, + resid
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8Args p) {
-    constexpr int BK = 128, TILE = 128 * BK;          // bytes of one operand tile
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [buf][W | A]
+// EPI 0: bias; 1: bias + GELU; 2: bias, * gamma, + resid.  TW: 32 x 32 MFMA tiles per wave and side: 2 -> 128 x 128
+// workgroup tile (64 KiB of LDS, 2 workgroups per CU), 4 -> 256 x 256 (128 KiB, one per CU, 256 accumulator registers
+// per lane): per K-tile a wave then issues 32 scaled MFMAs (2048 cycles) against 64 KiB of LDS-DMA per CU, i.e. the
+// L2 -> LDS stream (measured ~42 B/clk per CU, tools/dma_depth.hip) stays under the matrix pipe.
+template <int EPI, int TW>
+__global__ __launch_bounds__(256, TW == 2 ? 2 : 1) void gemm_fp8_kernel(const Fp8Args p) {
+    constexpr int BK = 128, BT = 64 * TW, TILE = BT * BK;          // rows and bytes of one operand tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [buf][W | A], 4 * TILE bytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
@@ -157,57 +160,63 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8Args p) {
     const int group = id / per_group, within = id - group * per_group;
     const int rows_g = min(GM, p.ntm - group * GM);
     const int tn = within / rows_g, tm = group * GM + within - tn * rows_g;
-    const int m0 = tm * 128, n0 = tn * 128;
+    const int m0 = tm * BT, n0 = tn * BT;
     const int nkt = p.Kp / BK, nsb = p.Kp >> 5;
+    constexpr int WR = 32 * TW;   // rows of a wave's MFMA tiles (2 waves per side)
+    constexpr int SR = 16 * TW;   // rows a wave stages of each operand tile (4 waves per tile)
 
-    // staging: a wave-instruction lands 8 rows x 128 B; wave w stages rows 32 w .. 32 w + 31 of both tiles
+    // staging: a wave-instruction lands 8 rows x 128 B; wave w stages rows SR w .. SR w + SR - 1 of both tiles.
+    // (wave-uniform 64-bit base) + (per-lane 32-bit offset): the per-lane part is the clamped row and the swizzled chunk
     const int srow = lane >> 3, sch = lane & 7;
-    const unsigned char* wsrc[4];
-    const unsigned char* asrc[4];
+    unsigned woff[SR / 8], aoff[SR / 8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = 32 * wave + 8 * j + srow;
+    for (int j = 0; j < SR / 8; ++j) {
+        const int row = SR * wave + 8 * j + srow;
         const int c = sch ^ ((row >> 1) & 7);
-        wsrc[j] = p.W + (long)min(n0 + row, p.N - 1) * p.Kp + c * 16;
-        asrc[j] = p.A + (long)min(m0 + row, p.M - 1) * p.Kp + c * 16;
+        woff[j] = (unsigned)((long)(min(n0 + row, p.N - 1) - n0) * p.Kp + c * 16);
+        aoff[j] = (unsigned)((long)(min(m0 + row, p.M - 1) - m0) * p.Kp + c * 16);
     }
+    const unsigned char* wbase = p.W + (long)n0 * p.Kp;
+    const unsigned char* abase = p.A + (long)m0 * p.Kp;
     auto issue = [&](int buf, int kt) {
         char* wb = smem + buf * 2 * TILE;
         char* ab = wb + TILE;
+        const unsigned char* wk = wbase + (long)kt * BK;
+        const unsigned char* ak = abase + (long)kt * BK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[j] + (long)kt * BK), (lds_void*)(wb + (32 * wave + 8 * j) * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(asrc[j] + (long)kt * BK), (lds_void*)(ab + (32 * wave + 8 * j) * 128), 16, 0, 0);
+        for (int j = 0; j < SR / 8; ++j) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wk + woff[j]), (lds_void*)(wb + (SR * wave + 8 * j) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(ak + aoff[j]), (lds_void*)(ab + (SR * wave + 8 * j) * 128), 16, 0, 0);
         }
     };
     // E8M0 dwords of this lane's rows: [tile i of W, tile j of A], one dword per K-tile
-    const unsigned* wsc[2];
-    const unsigned* asc[2];
+    const unsigned* wsc[TW];
+    const unsigned* asc[TW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        wsc[i] = reinterpret_cast<const unsigned*>(p.Ws + (long)min(n0 + wn * 64 + i * 32 + l31, p.N - 1) * nsb);
-        asc[i] = reinterpret_cast<const unsigned*>(p.As + (long)min(m0 + wm * 64 + i * 32 + l31, p.M - 1) * nsb);
+    for (int i = 0; i < TW; ++i) {
+        wsc[i] = reinterpret_cast<const unsigned*>(p.Ws + (long)min(n0 + wn * WR + i * 32 + l31, p.N - 1) * nsb);
+        asc[i] = reinterpret_cast<const unsigned*>(p.As + (long)min(m0 + wm * WR + i * 32 + l31, p.M - 1) * nsb);
     }
-    f32x16 acc[2][2];
+    f32x16 acc[TW][TW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    unsigned swn[2], san[2];
+    unsigned swn[TW], san[TW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TW; ++i) {
         swn[i] = wsc[i][0];
         san[i] = asc[i][0];
     }
     issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        unsigned sw[2], sa[2];
+        unsigned sw[TW], sa[TW];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TW; ++i) {
             sw[i] = swn[i] >> (8 * lh);
             sa[i] = san[i] >> (8 * lh);
         }
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8Args p) {
         if (kt + 1 < nkt) {
             issue(cur ^ 1, kt + 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TW; ++i) {
                 swn[i] = wsc[i][kt + 1];
                 san[i] = asc[i][kt + 1];
             }
@@ -225,10 +234,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8Args p) {
         const char* ab = wb + TILE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            i32x8 wf[2], af[2];
+            i32x8 wf[TW], af[TW];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int wr = wn * 64 + i * 32 + l31, ar = wm * 64 + i * 32 + l31;
+            for (int i = 0; i < TW; ++i) {
+                const int wr = wn * WR + i * 32 + l31, ar = wm * WR + i * 32 + l31;
                 // operand image of v_mfma_scale_f32_32x32x64_f8f6f4 (probed with one-hot rows, tools/dbg_fp8.py): the 64 K
                 // of a step are two 32-element scale blocks; lane (row, lh) holds elements 16 lh .. 16 lh + 15 of block 0
                 // in its first 16 bytes and of block 1 in its second 16 bytes; block 0's E8M0 scale is taken from the
@@ -242,9 +251,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8Args p) {
                 af[i] = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TW; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < TW; ++j) {
                     if (ks == 0)
                         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[i], af[j], acc[i][j], 0, 0, 0, (int)sw[i], 0, (int)sa[j]);
                     else
@@ -255,14 +264,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8Args p) {
 
     // D[n][m]: lane (m = l31, lh), register r -> n = (r & 3) + 8 (r >> 2) + 4 lh: 4 consecutive columns per group
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + wm * 64 + j * 32 + l31;
+    for (int j = 0; j < TW; ++j) {
+        const int m = m0 + wm * WR + j * 32 + l31;
         if (m >= p.M) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TW; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * g + 4 * lh;
+                const int n = n0 + wn * WR + i * 32 + 8 * g + 4 * lh;
                 if (n >= p.N) continue;      // N % 4 == 0 (checked by the launcher)
                 float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (p.bias) {
@@ -302,14 +311,36 @@ int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws
     p.A = (const unsigned char*)A; p.As = (const unsigned char*)As; p.W = (const unsigned char*)W; p.Ws = (const unsigned char*)Ws;
     p.M = M; p.N = N; p.Kp = (int)align_up((size_t)K, 128);
     p.bias = bias; p.gamma = gamma; p.resid = resid; p.ldr = ldr; p.out = out; p.out_dtype = out_dtype; p.ldo = ldo;
-    p.ntm = (int)cdiv(M, 128); p.ntn = (int)cdiv(N, 128);
+    // 256 x 256 tiles where the K loop is long enough to pay for the larger epilogue and they fill most of the chip
+    // (measured at M = 43968, tools/mb_fp8.py: K = 4096 -> 1207 vs 1071 TFLOP/s, K = 1024 -> 736-803 vs 828-865),
+    // else 128 x 128 (two workgroups per CU).  SKIMI_FP8_TILE=128|256 forces a choice (A/B timing).
+    static const int force_tile = getenv("SKIMI_FP8_TILE") ? atoi(getenv("SKIMI_FP8_TILE")) : 0;
+    const bool big = force_tile ? force_tile == 256 : (K >= 2048 && cdiv(M, 256) * cdiv(N, 256) >= 200);
+    const int bt = big ? 256 : 128;
+    p.ntm = (int)cdiv(M, bt); p.ntn = (int)cdiv(N, bt);
     const long nblk = (long)p.ntm * p.ntn;
     SKIMI_CHECK_ARG(nblk < (1l << 31), "gemm_fp8: grid too large");
+    SKIMI_CHECK_ARG((long)bt * p.Kp < (1l << 32), "gemm_fp8: K too large for 32-bit staging offsets");
+    const int epi = gamma ? 2 : act == SKIMI_ACT_GELU ? 1 : 0;
     const bool prof = prof_armed(PROF_GEMM, N);
     if (prof) prof_before(st);
-    if (gamma) hipLaunchKernelGGL(gemm_fp8_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, st, p);
-    else if (act == SKIMI_ACT_GELU) hipLaunchKernelGGL(gemm_fp8_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(gemm_fp8_kernel<0>, dim3((unsigned)nblk), dim3(256), 0, st, p);
+#define SKIMI_FP8_LAUNCH(E, T)                                                                                          \
+    do {                                                                                                                \
+        constexpr int lds = 4 * 64 * T * 128;                                                                           \
+        static bool attr = false;                                                                                       \
+        if (lds > 64 * 1024 && !attr) {                                                                                 \
+            SKIMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<E, T>),                         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));                            \
+            attr = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL((gemm_fp8_kernel<E, T>), dim3((unsigned)nblk), dim3(256), lds, st, p);                       \
+    } while (0)
+    if (big) {
+        if (epi == 2) SKIMI_FP8_LAUNCH(2, 4); else if (epi == 1) SKIMI_FP8_LAUNCH(1, 4); else SKIMI_FP8_LAUNCH(0, 4);
+    } else {
+        if (epi == 2) SKIMI_FP8_LAUNCH(2, 2); else if (epi == 1) SKIMI_FP8_LAUNCH(1, 2); else SKIMI_FP8_LAUNCH(0, 2);
+    }
+#undef SKIMI_FP8_LAUNCH
     if (prof) prof_after(st, 2.0 * M * (double)N * K, (double)M * K + (double)N * K + (double)M * N * (out_dtype == SKIMI_F32 ? 4 : 2));
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
