@@ -268,7 +268,7 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
 }
 
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
-                     hipStream_t st, int q_prescaled) {
+                     hipStream_t st, int q_prescaled, void* x3_scratch, size_t x3_scratch_bytes) {
     SKIMI_CHECK_ARG(qkv && out, "skimi_attention: null buffer");
     AttnArgs a;
     const long C = (long)heads * head_dim;
@@ -288,7 +288,17 @@ int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, 
     a.head_dim = head_dim;
     a.scale = 1.0f / sqrtf((float)head_dim);
     a.q_prescaled = dtype == SKIMI_F32 ? 0 : q_prescaled;
-    if (dtype == SKIMI_F32) return attention_f32_launch(a, st);
+    if (dtype == SKIMI_F32) {
+        // fp32-accurate mode: the bf16x3 kernel when the caller lends scratch for the hi / lo planes (SKIMI_ATTN_X3=0: the
+        // exact-fp32 MFMA kernel, A/B timing and a cross-check in the tests)
+        static const bool dyn = getenv("SKIMI_ENV_DYNAMIC") && atoi(getenv("SKIMI_ENV_DYNAMIC"));
+        static int use_x3 = -1;
+        if (use_x3 < 0 || dyn) use_x3 = getenv("SKIMI_ATTN_X3") ? atoi(getenv("SKIMI_ATTN_X3")) : 1;
+        const long tokens = (long)batch * seq;
+        if (use_x3 && head_dim == 64 && x3_scratch && x3_scratch_bytes >= attention_x3_scratch_bytes(tokens, 3 * C))
+            return attention_x3_launch(a, tokens, 3 * C, x3_scratch, x3_scratch_bytes, st);
+        return attention_f32_launch(a, st);
+    }
     return attention_bf16_launch(a, st);
 }
 

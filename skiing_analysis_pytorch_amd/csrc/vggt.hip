@@ -289,6 +289,14 @@ struct Packer {
         b.proj = linear(p + ".attn.proj", C, C, prec);
         b.fc1 = linear(p + ".mlp.fc1", hidden, C, prec);
         b.fc2 = linear(p + ".mlp.fc2", C, hidden, prec);
+        // fp32-accurate mode: the four Linears also as bf16x3 records, so that launches that fill the chip with 256-row
+        // tiles (from one 8-view time step on) run on the LDS-DMA bf16x3 kernel (gemm_x3dma.hip) instead of the generic one
+        if (!rc && prec == SKIMI_PREC_BF16X3 && C % 32 == 0 && hidden % 32 == 0) {
+            add_records(b.qkv);
+            add_records(b.proj);
+            add_records(b.fc1);
+            add_records(b.fc2);
+        }
         if (fp8) {
             add_fp8(b.qkv, p + ".attn.qkv", 3 * C, C);
             add_fp8(b.fc1, p + ".mlp.fc1", hidden, C);
@@ -444,7 +452,10 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
                                   c.tabs->rope_cos, c.tabs->rope_sin, c.tabs->rope_npos, c.st, q_scale,
                                   adt == SKIMI_BF16 && C / heads == 64 ? &q_scaled : nullptr);
     }
-    if (!c.rc && !c.dry()) c.rc = attention_launch(b.qkv, b.ao, adt, batch, seq, heads, C / heads, c.st, q_scaled);
+    // fp32-accurate mode: the MLP's hidden buffer (M x hidden fp32, idle until fc1) lends the hi / lo planes of qkv
+    if (!c.rc && !c.dry())
+        c.rc = attention_launch(b.qkv, b.ao, adt, batch, seq, heads, C / heads, c.st, q_scaled, adt == SKIMI_F32 ? b.hid : nullptr,
+                                adt == SKIMI_F32 ? (size_t)M * hidden * 4 : 0);
     {
         auto d = c.desc(w.proj, b.ao, adt, C, M, x, SKIMI_F32, C);
         d.gamma = w.ls1; d.resid = x; d.ldr = C;
