@@ -15,7 +15,7 @@ for f in files:
     dur += [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs]
 ns = sum(dur) / len(dur)
 c = out["counters"]
-n_mfma = 4.0 * 4 * 16 * 10992 * 10992 * 64 / 32768
+n_mfma = 4.0 * 4 * 16 * 10992 * 10992 * 64 / 32768 * (34.0 / 32.0)   # + the 2 reference MFMAs per 64-key tile and wave
 out["avg_launch_us_under_pmc"] = ns / 1e3
 out["mfma_instructions_per_launch"] = n_mfma
 out["note_units"] = ("SQ_VALU_MFMA_BUSY_CYCLES counts MFMA-pipe cycles summed over all SIMDs (= 32 x N_mfma for "
