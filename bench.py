@@ -231,6 +231,11 @@ def main():
                                               "source, matched by its sha256; null when the kernel changed since)",
                             "avg_launch_us": avg_s * 1e6, "launches": int(n.value),
                             "flops_per_launch": flops_per_launch}
+        pk = measured_peaks()
+        if pk:   # what a register-only MFMA loop delivers on this part (tools/peaks.hip): context for `frac`, which stays on the datasheet peak
+            line["roofline"]["peak_measured"] = {"unit": "TFLOP/s", "random_operands": pk["random_operands"], "zero_operands": pk["zero_operands"],
+                                                 "frac_of_random_operand_peak": ach / pk["random_operands"],
+                                                 "source": "static: profiles/r02_peaks.json (tools/peaks.hip, register-only v_mfma_f32_32x32x16_bf16 loop)"}
     if rank == 0 and world == 1 and NS > 1 and "roofline" in line:
         # outside the timed region: the same kernel with the chip to itself (one batch, one stream)
         _lib.check(lib.skimi_profile_start(1, seq_global), "profile_start")
@@ -390,6 +395,14 @@ def vp3d_leg(dev, cpu=True):
         res["cpu_oracle"] = {"s_per_clip_with_flip_tta": tc, "cores": threads,
                              "max_abs_joint_err_vs_hip": float(abs(got - ref).max())}
     return res
+
+
+def measured_peaks():
+    f = Path(__file__).resolve().parent / "profiles" / "r02_peaks.json"
+    try:
+        return json.loads(f.read_text())["mfma_bf16_32x32x16_register_loop_TFLOPs"]
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def attn_kernel_sha():
