@@ -150,3 +150,19 @@ def test_vggt_fullsize_fp32_mode_vs_oracle(H, W, head, monkeypatch):
         rel2 = (out2[k].cpu() - ref[k]).abs() / (ref[k].abs() + 1.0)
         assert rel2.max().item() < 1e-3, (k, rel2.max().item())
         assert ((out2[k] - out[k]).abs() / (out[k].abs() + 1.0)).max().item() < 1e-4
+
+
+def test_parity_mode_attention_kernels_agree(golden_dir, monkeypatch):
+    """The parity mode's attention on the bf16 matrix pipe (attention_x3.hip: hi + lo operands, three MFMAs per
+    product) against the exact-fp32 MFMA kernel (SKIMI_ATTN_X3=0) on the same model: both meet the golden, and they
+    agree with each other far inside the bar."""
+    g, cfg, sd, images = _load(golden_dir, "tiny_dino")
+    m = vggt.VGGT(config=cfg, prec=PREC_BF16X3, head_prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    a = m(images.cuda(), want={"camera"}, return_tokens=True)
+    monkeypatch.setenv("SKIMI_ATTN_X3", "0")      # re-read per launch: conftest sets SKIMI_ENV_DYNAMIC=1
+    b = m(images.cuda(), want={"camera"}, return_tokens=True)
+    for o in (a, b):
+        assert _maxerr(o["tokens_last"].cpu(), g["tokens_last"]) < 1e-3
+    assert _maxerr(a["tokens_last"].cpu(), b["tokens_last"].cpu()) < 2e-4
+    assert _maxerr(a["pose_enc"].cpu(), b["pose_enc"].cpu()) < 1e-4

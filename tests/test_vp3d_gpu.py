@@ -99,3 +99,29 @@ def test_vp3d_short_input_rejected():
     m = _model([3, 3, 3], False, PREC_BF16X3)
     with pytest.raises(_lib.SkimiError):
         m(torch.zeros(1, 26, 17, 2, device="cuda"))
+
+
+@pytest.mark.parametrize("fw,causal", [([3, 3, 3], False), ([3, 3, 3, 3, 3], False), ([3, 3, 3], True), ([3, 5, 3], False)])
+def test_vp3d_small_batches_on_the_streaming_path(fw, causal, monkeypatch):
+    """B = 1 .. a few clips run on the weight-streaming kernels (vp3d_stream.hip: one launch per convolution, row splits
+    per clip, activations loaded once for all taps; filter width 5 and the large dilations of RF 243 take the per-tap
+    gather kernel): every clip of a small batch equals its single-clip result, both agree with the oracle, and the
+    generic GEMM chain (SKIMI_VP3D_STREAM=0 in a fresh handle's process is not possible here, so the oracle is the
+    common reference).  The streaming path has no atomics: two runs are bit-identical."""
+    from oracle import vp3d_oracle
+
+    sd = W.make_vp3d_state_dict(seed=0, filter_widths=fw)
+    m = vp3d.TemporalModel(17, 2, 17, fw, causal=causal, prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    rf = m.receptive_field()
+    for B, frames in ((1, rf), (1, rf + 242), (3, rf + 100), (5, rf + 17)):
+        x = torch.randn(B, frames, 17, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(B * 7 + frames))
+        out = m(x)
+        assert out.shape == (B, frames - rf + 1, 17, 3)
+        assert torch.equal(out, m(x))                                      # deterministic
+        with torch.no_grad():
+            ref = vp3d_oracle.temporal_model_forward(sd, x.cpu(), fw, causal)
+        assert (out.cpu() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+        for i in range(B):
+            one = m(x[i:i + 1].contiguous())
+            assert (out[i] - one[0]).abs().max().item() < 1e-5 * max(1.0, one.abs().max().item())
