@@ -637,6 +637,198 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const GemmArgs p) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// MXFP8 on the same single-stream loop (BASELINE config 5).  A K-tile is again 128 bytes per row -- now 128 e4m3
+// elements -- so tile geometry, LDS ring, LDS-DMA and fragment addresses are gemm256w4_kernel's unchanged; what
+// changes is the matrix instruction: one v_mfma_scale_f32_32x32x64_f8f6f4 (64 cycles) consumes the fragments of TWO
+// bf16 k-steps, because its operand image (a lane's first 16 bytes = elements 16 lh .. of scale block 0, the next 16
+// = of scale block 1; gemm_fp8.hip) is exactly chunk (4 ks + lh) followed by chunk (4 ks + 2 + lh), i.e. the bf16
+// kernel's reads of k-steps 2 ks and 2 ks + 1.  So a K-tile is two fp8 k-steps of 16 MFMAs each, every one with 16
+// fragment reads (the next k-step's) and up to 16 vector-memory instructions (LDS-DMA of K-tile kt + 2, the E8M0
+// dwords of K-tile kt + 1 read straight from L2) dealt between its MFMAs: the same bytes per K-tile as the bf16
+// loop, the same MFMA cycles, twice the K.  The E8M0 byte of (row, scale block 2 ks + lh) is picked by a per-lane
+// shift (8 lh) and the instruction's op_sel (0 / 2).  Epilogues: epilogue256 (same accumulator layout).
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm256w4_fp8_kernel(const GemmArgs p) {
+    constexpr int RB = 128, BK = 128, PIECE = 128 * RB, NSLOT = 10;   // BK in bytes = elements
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int tm, tn;
+    tile_coords256(p, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nkt = p.K / BK;
+    const unsigned char* src[4][4];   // [q][j]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (4 * wave + j) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            src[q][j] = q < 2 ? (const unsigned char*)p.A + (long)min(m0 + 128 * q + row, p.M - 1) * p.lda + c * 16
+                              : (const unsigned char*)p.W + (long)min(n0 + 128 * (q - 2) + row, p.N - 1) * p.ldw + c * 16;
+        }
+    auto issue = [&](int q, int kt, int slot) {
+        char* base = smem + slot * PIECE + (4 * wave) * 8 * RB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(src[q][j] + (long)kt * BK), (lds_void*)(base + j * 8 * RB), 16, 0, 0);
+    };
+    // E8M0 dwords (4 scale blocks of a K-tile) of this lane's rows: A rows 128 wr + 32 i + l31, W rows 128 wc + 32 j + l31
+    const unsigned* asc[4];
+    const unsigned* wsc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asc[i] = reinterpret_cast<const unsigned*>(p.a_scales + (long)min(m0 + 128 * wr + 32 * i + l31, p.M - 1) * p.lsa);
+        wsc[i] = reinterpret_cast<const unsigned*>(p.w_scales + (long)min(n0 + 128 * wc + 32 * i + l31, p.N - 1) * p.lsw);
+    }
+    unsigned sa[4], sw[4], san[4], swn[4];
+    auto load_scales = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            san[i] = asc[i][kt];
+            swn[i] = wsc[i][kt];
+        }
+    };
+    auto take_scales = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sa[i] = san[i] >> (8 * lh);
+            sw[i] = swn[i] >> (8 * lh);
+        }
+    };
+
+    // fragment reads of one fp8 k-step = the bf16 kernel's reads of k-steps 2 ks and 2 ks + 1
+    const int t = lh ^ ((l31 >> 1) & 7);
+    const int lane_off = l31 * RB;
+    i32x4_t fa0[2][4], fb0[2][4], fa1[2][4], fb1[2][4];
+    auto readp = [&](int sb, int ks, i32x4_t (&fa)[2][4], i32x4_t (&fb)[2][4]) {
+        int sA = sb + wr, sW = sb + 2 + wc;
+        sA = sA >= NSLOT ? sA - NSLOT : sA;
+        sW = sW >= NSLOT ? sW - NSLOT : sW;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s = 2 * ks + h;
+            const char* pa = smem + sA * PIECE + lane_off + (((2 * s) ^ t) << 4);
+            const char* pw = smem + sW * PIECE + lane_off + (((2 * s) ^ t) << 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[h][i] = *reinterpret_cast<const i32x4_t*>(pa + i * 32 * RB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fb[h][i] = *reinterpret_cast<const i32x4_t*>(pw + i * 32 * RB);
+        }
+    };
+
+    f32x16 acc[2][4][2];   // [column half h][row block i][column block j]: columns 64 h + 32 j
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+#define SKIMI_F8_CAT(F, I) i32x8_t{F[0][I][0], F[0][I][1], F[0][I][2], F[0][I][3], F[1][I][0], F[1][I][1], F[1][I][2], F[1][I][3]}
+#define SKIMI_F8_MFMA(FA, FB, OPSEL)                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 4; ++i)                  \
+        acc[j >> 1][i][j & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                 \
+            SKIMI_F8_CAT(FA, i), SKIMI_F8_CAT(FB, j), acc[j >> 1][i][j & 1], 0, 0, OPSEL, (int)sa[i], OPSEL, (int)sw[j])
+
+    // prologue: the scales of K-tile 0, then K-tiles 0 and 1 whole
+    load_scales(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue(q, 0, q);
+    if (nkt > 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue(q, 1, 4 + q);
+        SKIMI_VMCNT(16);
+    } else {
+        SKIMI_VMCNT(0);
+    }
+    take_scales();
+    SKIMI_BAR();
+    int sb = 0;   // slot of piece 0 of K-tile kt
+    readp(sb, 0, fa0, fb0);
+#define SKIMI_F8_HEAD()                       \
+    do {                                      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);   \
+        __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+    // 16 MFMAs with the next k-step's 16 fragment reads (2 per MFMA) and NV vector-memory instructions behind them
+#define SKIMI_F8_TAIL(NV)                                                          \
+    do {                                                                           \
+        _Pragma("unroll") for (int g = 0; g < 8; ++g) {                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                     \
+        }                                                                          \
+        _Pragma("unroll") for (int g = 0; g < 8; ++g) {                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+            if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x010, (NV + 7) / 8, 0); \
+        }                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    } while (0)
+    // one K-tile; N1 / N2: K-tiles kt+1 / kt+2 exist; PW: vmcnt that leaves only what was issued AFTER this tile's scales
+#define SKIMI_F8_KTILE(N1, N2, PW)                                                  \
+    do {                                                                            \
+        int s8 = sb + 8, s9 = sb + 9, s1 = sb + 1, nsb = sb + 4;                    \
+        s8 = s8 >= NSLOT ? s8 - NSLOT : s8;                                         \
+        s9 = s9 >= NSLOT ? s9 - NSLOT : s9;                                         \
+        s1 = s1 >= NSLOT ? s1 - NSLOT : s1;                                         \
+        nsb = nsb >= NSLOT ? nsb - NSLOT : nsb;                                     \
+        /* k-step 0: scale blocks 0 / 1 */                                          \
+        SKIMI_F8_HEAD();                                                            \
+        readp(sb, 1, fa1, fb1);                                                     \
+        if (N2) {                                                                   \
+            issue(0, kt + 2, s8);                                                   \
+            issue(1, kt + 2, s9);                                                   \
+        }                                                                           \
+        SKIMI_F8_MFMA(fa0, fb0, 0);                                                 \
+        SKIMI_F8_TAIL((N2 ? 8 : 0));                                                \
+        /* k-step 1: scale blocks 2 / 3 */                                          \
+        SKIMI_F8_HEAD();                                                            \
+        if (N1) {                                                                   \
+            if (N2) SKIMI_VMCNT(8); else SKIMI_VMCNT(0);                            \
+            SKIMI_BAR();                                                            \
+            readp(nsb, 0, fa0, fb0);                                                \
+            load_scales(kt + 1);                                                    \
+            if (N2) {                                                               \
+                issue(2, kt + 2, sb);                                               \
+                issue(3, kt + 2, s1);                                               \
+            }                                                                       \
+        }                                                                           \
+        SKIMI_F8_MFMA(fa1, fb1, 2);                                                 \
+        if (N1) SKIMI_F8_TAIL((N2 ? 16 : 8)); else __builtin_amdgcn_sched_barrier(0); \
+        if (N1) {                                                                   \
+            SKIMI_VMCNT(PW);   /* the scales of K-tile kt + 1 have landed */         \
+            take_scales();                                                          \
+        }                                                                           \
+        sb = nsb;                                                                   \
+    } while (0)
+    int kt = 0;
+    for (; kt + 2 < nkt; ++kt) SKIMI_F8_KTILE(true, true, 8);
+    if (kt + 1 < nkt) {
+        SKIMI_F8_KTILE(true, false, 0);
+        ++kt;
+    }
+    SKIMI_F8_KTILE(false, false, 0);
+#undef SKIMI_F8_KTILE
+#undef SKIMI_F8_HEAD
+#undef SKIMI_F8_TAIL
+#undef SKIMI_F8_MFMA
+#undef SKIMI_F8_CAT
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    SKIMI_BAR();   // nobody reads operand pieces any more: the epilogue slabs alias slots 0 and 1
+
+    epilogue256<4, EPI, 4>(p, acc[0], smem, wave, lane, wr, 2 * wc, m0, n0);
+    epilogue256<4, EPI, 4>(p, acc[1], smem, wave, lane, wr, 2 * wc + 1, m0, n0);
+}
+
 // integer environment switch; read once, or on every call under SKIMI_ENV_DYNAMIC=1 (lets a timing
 // script alternate variants inside one process: boxes and thermal state differ by several percent)
 static int env_int(const char* name, int dflt, int& cache, bool& have) {
@@ -787,6 +979,39 @@ int gemm256_launch(GemmArgs& a, hipStream_t st) {
     if (epi == 2) return launch256<4, 2>(a, st);
     if (epi == 3) return launch256<4, 3>(a, st);
     return launch256<4, 0>(a, st);
+}
+
+template <int EPI>
+static int launch256w4_fp8(GemmArgs& a, hipStream_t st) {
+    constexpr size_t lds = 10ull * 128 * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256w4_fp8_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(gemm256w4_fp8) failed: %s", hipGetErrorString(e));
+            return SKIMI_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    a.ntm = (int)cdiv(a.M, 256);
+    a.ntn = (int)cdiv(a.N, 256);
+    a.splitk = 1;
+    hipLaunchKernelGGL((gemm256w4_fp8_kernel<EPI>), dim3(a.ntm * a.ntn), dim3(256), lds, st, a);
+    SKIMI_LAUNCH_CHECK();
+    return SKIMI_OK;
+}
+
+// MXFP8 operands on the single-stream 256 x 256 loop.  The caller (gemm_fp8_launch) has checked the shape: K = Kp
+// (bytes per row, a multiple of 128), 16-byte aligned operands, one of the three compile-time epilogues.
+int gemm256_fp8_launch(GemmArgs& a, hipStream_t st) {
+    a.dbg = 0;
+    const int epi = epi_kind(a);
+    if (epi == 1) return launch256w4_fp8<1>(a, st);
+    if (epi == 2) return launch256w4_fp8<2>(a, st);
+    if (epi == 3) return launch256w4_fp8<3>(a, st);
+    set_error("gemm256_fp8: epilogue not supported");
+    return SKIMI_ERR_ARG;
 }
 
 }  // namespace skimi

@@ -41,6 +41,10 @@ struct GemmArgs {
     int dbg;           // diagnostics only (gemm256 ablation: bit0 skip staging, bit1 skip MFMA phase)
     unsigned short* out_rec;   // or NULL: result rows also as bf16x3 records [M][N/32][hi 32 | lo 32]
     long rec_row;              // elements per record row = N/32 * 64
+    // MXFP8 launches (gemm256w4_fp8_kernel): A / W are e4m3 payloads (lda / ldw in BYTES = Kp, K = Kp), scales E8M0
+    const unsigned char* a_scales;
+    const unsigned char* w_scales;
+    long lsa, lsw;             // bytes per scale row = Kp / 32
 };
 
 // columns n..n+3 of row m into the records (8-byte stores; 8 lanes fill one 128-byte record)
@@ -259,5 +263,6 @@ int split_planes_launch(const float* x, long ld, long rows, int C, void* hi, voi
 // fp32 [rows, C] -> records [rows][ceil(C/32)][hi 32 | lo 32] bf16 (operand form of the LDS-DMA bf16x3 kernel)
 int split_records_launch(const float* x, long ld, long rows, int C, void* rec, hipStream_t st, void* zpage = nullptr);
 int gemm256_launch(GemmArgs& a, hipStream_t st);
+int gemm256_fp8_launch(GemmArgs& a, hipStream_t st);   // MXFP8 operands on the single-stream 256 x 256 loop; a.K = Kp (bytes per row)
 
 }  // namespace skimi

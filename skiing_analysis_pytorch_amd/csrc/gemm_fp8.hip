@@ -21,6 +21,7 @@
 // the instruction's op_sel (0 / 2).
 // Epilogue (compile-time variants): bias; bias + erf-GELU; bias, LayerScale, residual (fp32, in place).
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -311,6 +312,30 @@ int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws
     p.A = (const unsigned char*)A; p.As = (const unsigned char*)As; p.W = (const unsigned char*)W; p.Ws = (const unsigned char*)Ws;
     p.M = M; p.N = N; p.Kp = (int)align_up((size_t)K, 128);
     p.bias = bias; p.gamma = gamma; p.resid = resid; p.ldr = ldr; p.out = out; p.out_dtype = out_dtype; p.ldo = ldo;
+    // Shapes that fill the chip with 256-row tiles and end in one of the three block epilogues (bias -> bf16; bias,
+    // GELU -> bf16; bias, LayerScale, fp32 residual -> fp32) run on the single-stream loop of gemm256.hip
+    // (gemm256w4_fp8_kernel).  SKIMI_FP8_W4=0 keeps them on this file's kernel (A/B timing).
+    {
+        static const bool dyn = getenv("SKIMI_ENV_DYNAMIC") && atoi(getenv("SKIMI_ENV_DYNAMIC"));
+        static int use_w4 = -1;
+        if (use_w4 < 0 || dyn) use_w4 = getenv("SKIMI_FP8_W4") ? atoi(getenv("SKIMI_FP8_W4")) : 1;
+        const bool epi_ok = (out_dtype == SKIMI_BF16 && !gamma && !resid && bias) || (out_dtype == SKIMI_F32 && gamma && resid && bias);
+        if (use_w4 && epi_ok && M >= 2048 && N >= 512 && N % 4 == 0 && cdiv(M, 256) * cdiv(N, 256) >= 160 &&
+            (((uintptr_t)A | (uintptr_t)W | (uintptr_t)As | (uintptr_t)Ws) & 15) == 0) {
+            GemmArgs g;
+            memset(&g, 0, sizeof g);
+            g.M = M; g.N = N; g.K = p.Kp;
+            g.A = A; g.W = W; g.lda = p.Kp; g.ldw = p.Kp;
+            g.a_scales = (const unsigned char*)As; g.w_scales = (const unsigned char*)Ws; g.lsa = p.Kp / 32; g.lsw = p.Kp / 32;
+            g.bias = bias; g.gamma = gamma; g.resid = resid; g.resid_dtype = SKIMI_F32; g.ldr = ldr;
+            g.act = act; g.out = out; g.out_dtype = out_dtype; g.ldo = ldo; g.vec4 = 1;
+            const bool prof2 = prof_armed(PROF_GEMM, N);
+            if (prof2) prof_before(st);
+            const int rc = gemm256_fp8_launch(g, st);
+            if (prof2) prof_after(st, 2.0 * M * (double)N * K, (double)M * K + (double)N * K + (double)M * N * (out_dtype == SKIMI_F32 ? 4 : 2));
+            return rc;
+        }
+    }
     // 256 x 256 tiles where the K loop is long enough to pay for the larger epilogue and they fill most of the chip
     // (measured at M = 43968, tools/mb_fp8.py: K = 4096 -> 1207 vs 1071 TFLOP/s, K = 1024 -> 736-803 vs 828-865),
     // else 128 x 128 (two workgroups per CU).  SKIMI_FP8_TILE=128|256 forces a choice (A/B timing).

@@ -36,7 +36,10 @@ def test_quant_mx_bit_exact(dtype, rows, K):
     assert np.array_equal(q.cpu().numpy(), qr)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 260, 384), (128, 128, 128), (1000, 3072, 1024), (77, 64, 4096)])
+# the last four shapes fill the chip with 256-row tiles and take the single-stream loop (gemm256w4_fp8_kernel): ragged M and N,
+# 1, 2, 5 and 8 K-tiles (the peeled iterations of its software pipeline)
+@pytest.mark.parametrize("M,N,K", [(300, 260, 384), (128, 128, 128), (1000, 3072, 1024), (77, 64, 4096),
+                                   (5000, 2304, 1024), (4100, 2500, 640), (4096, 4096, 128), (4200, 2560, 256)])
 def test_gemm_fp8_matches_dequantised_product(M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn((M, K), generator=g) * (1 + 3 * torch.rand((M, 1), generator=g))
