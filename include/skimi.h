@@ -42,6 +42,7 @@ extern "C" {
 #define SKIMI_F32 0
 #define SKIMI_BF16 1
 #define SKIMI_BF16X3_REC 2 /* skimi_gemm_desc.a_dtype only: A already split into [hi 32 | lo 32] records */
+#define SKIMI_FP8MX 3      /* skimi_gemm_fp8 out_dtype only: the result as MXFP8 (payload in out, E8M0 scales in out_scales) */
 
 /* arithmetic mode of the MFMA contractions
  *   SKIMI_PREC_BF16   : operands rounded to bf16, one v_mfma_f32_32x32x16_bf16 per
@@ -176,13 +177,21 @@ int skimi_gemm(const skimi_gemm_desc* d, void* stream);
  * amax / scale <= 448, so no element clips; 0 for an all-zero block). */
 int skimi_quant_mx(const void* x, int32_t dtype, int64_t ldx, int64_t rows, int32_t K, void* payload, void* scales,
                    void* stream);
+/* LayerNorm(C, affine, eps) of fp32 rows (vggt/vggt/layers/block.py:77-98's norm1 / norm2) written directly as the
+ * MXFP8 operand of the following skimi_gemm_fp8: payload [rows][C], scales [rows][C / 32]; the same bytes as
+ * skimi_quant_mx of the fp32 LayerNorm result.  C a multiple of 256 (<= 2048), ldx % 4 == 0. */
+int skimi_layernorm_mx(const float* x, int64_t ldx, int64_t rows, int32_t C, const float* gamma, const float* beta,
+                       float eps, void* payload, void* scales, void* stream);
 /* out[m][n] = epilogue(sum_k A[m][k] W[n][k]) on v_mfma_scale_f32_32x32x64_f8f6f4, both operands as written by
  * skimi_quant_mx (nn.Linear layout for W: [N, K]).  Epilogue: + bias[n] (or NULL); act = SKIMI_ACT_NONE or
  * SKIMI_ACT_GELU; or, with gamma != NULL, gamma[n] * (. + bias[n]) + resid[m][n] (fp32, row stride ldr; may alias
- * out: block.py:77-98's LayerScale + residual).  out fp32 or bf16, row stride ldo; N, ldo, ldr multiples of 4. */
+ * out: block.py:77-98's LayerScale + residual).  out fp32 or bf16, row stride ldo; N, ldo, ldr multiples of 4.
+ * out_dtype SKIMI_FP8MX (with out_scales != NULL; large shapes with the GELU epilogue only, N % 128 == 0): the
+ * result is written directly in the operand form of the NEXT skimi_gemm_fp8 -- payload [M][N] bytes in out
+ * (ldo = N) and scales [M][N / 32] in out_scales -- so the MLP's hidden activation never exists in bf16. */
 int skimi_gemm_fp8(const void* A, const void* A_scales, const void* W, const void* W_scales, int32_t M, int32_t N,
                    int32_t K, const float* bias, int32_t act, const float* gamma, const float* resid, int64_t ldr,
-                   void* out, int32_t out_dtype, int64_t ldo, void* stream);
+                   void* out, int32_t out_dtype, int64_t ldo, void* out_scales, void* stream);
 
 /* Direct 3x3 convolution (stride 1, pad 1) of a channels-last image to 32 output channels in the
  * fp32-accurate mode: the last conv of the DPT heads at full resolution

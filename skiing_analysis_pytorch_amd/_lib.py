@@ -13,6 +13,7 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libskimi.so"
 
 F32, BF16 = 0, 1
 BF16X3_REC = 2   # skimi_gemm_desc.a_dtype: A already split into bf16x3 records
+FP8MX = 3        # skimi_gemm_fp8 out_dtype: the result as MXFP8 payload + scales
 PREC_BF16, PREC_BF16X3, PREC_FP8 = 0, 1, 2   # PREC_FP8: VGGT aggregator only (MXFP8 qkv / fc1 / fc2)
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
 
@@ -67,8 +68,9 @@ _SIGNATURES = {
                                     C.POINTER(C.c_double)]),
     "skimi_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "skimi_quant_mx": (C.c_int, [_vp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp]),
+    "skimi_layernorm_mx": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     "skimi_gemm_fp8": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, _vp, _vp, C.c_int64,
-                                 _vp, C.c_int32, C.c_int64, _vp]),
+                                 _vp, C.c_int32, C.c_int64, _vp, _vp]),
     "skimi_split_planes": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp, _vp]),
     "skimi_split_records": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int32, _vp, _vp]),
     "skimi_resample_u8": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, C.c_int32, _vp]),

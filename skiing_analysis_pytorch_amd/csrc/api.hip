@@ -146,11 +146,16 @@ int skimi_quant_mx(const void* x, int32_t dtype, int64_t ldx, int64_t rows, int3
     return quant_mx_launch(x, dtype, (long)ldx, (long)rows, K, payload, scales, (hipStream_t)stream);
 }
 
+int skimi_layernorm_mx(const float* x, int64_t ldx, int64_t rows, int32_t C, const float* gamma, const float* beta,
+                       float eps, void* payload, void* scales, void* stream) {
+    return layernorm_mx_launch(x, ldx, rows, C, gamma, beta, eps, payload, scales, (hipStream_t)stream);
+}
+
 int skimi_gemm_fp8(const void* A, const void* A_scales, const void* W, const void* W_scales, int32_t M, int32_t N,
                    int32_t K, const float* bias, int32_t act, const float* gamma, const float* resid, int64_t ldr,
-                   void* out, int32_t out_dtype, int64_t ldo, void* stream) {
+                   void* out, int32_t out_dtype, int64_t ldo, void* out_scales, void* stream) {
     return gemm_fp8_launch(A, A_scales, W, W_scales, M, N, K, bias, act, gamma, resid, (long)ldr, out, out_dtype, (long)ldo,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, out_scales);
 }
 
 int skimi_layernorm(const float* x, const float* x2, int64_t ldx, int64_t rows, int32_t C,

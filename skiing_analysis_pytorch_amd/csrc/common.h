@@ -64,6 +64,34 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
 __device__ __forceinline__ float bf2f(unsigned short b) {
     return __builtin_bit_cast(float, ((unsigned int)b) << 16);
 }
+// MXFP8 (gemm_fp8.hip): E8M0 byte of a 32-element block = smallest power of two with amax / scale <= 448 (0: all zero),
+// and its inverse as an exact power of two
+__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
+    if (!(amax > 0.f)) return 0u;
+    const float t = amax * (1.0f / 448.0f);
+    const unsigned u = __float_as_uint(t);
+    const int e = (int)((u >> 23) & 0xFF) - 127 + ((u & 0x7FFFFF) ? 1 : 0);
+    return (unsigned)min(max(e + 127, 1), 254);
+}
+__device__ __forceinline__ float mx_inv_scale(unsigned sb) { return sb ? __uint_as_float((unsigned)(254 - (int)sb) << 23) : 0.f; }
+// four values -> four e4m3 bytes (element 0 in the low byte)
+__device__ __forceinline__ int mx_pack4(float a, float b, float c, float d, float inv) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a * inv, b * inv, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c * inv, d * inv, w, true);
+    return w;
+}
+// maximum over the 8 lanes lane & ~7 .. lane | 7 (a 32-element block when every lane holds 4 consecutive elements)
+// DPP lane permutes (quad_perm [1,0,3,2], [2,3,0,1], then row_half_mirror: lane i <-> 7 - i of each 8), no LDS traffic
+__device__ __forceinline__ float max8(float v) {
+    int x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, true)));
+    x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, true)));
+    x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, true)));
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -117,6 +117,7 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT]
         return;
     }
     if (EPI != 0 && interior) {
+        const bool mx = EPI == 3 && p.out_dtype == SKIMI_FP8MX;   // MXFP8 result: 8 lanes = one 32-column scale block of a row
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             SKIMI_ACC_TO_SLAB(i);
@@ -125,12 +126,21 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT]
 #pragma unroll
             for (int it = 0; it < 8; ++it)
                 v[it] = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + 4 * (lane & 15)]);
+            unsigned sb_mine = 0;   // MXFP8: the scale of pass it = lane & 7, so that the 64 scale bytes of the slab go out in one store
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 float y0 = v[it].x + bs.x, y1 = v[it].y + bs.y, y2 = v[it].z + bs.z, y3 = v[it].w + bs.w;
                 if (EPI == 3) {
                     const f32x2_t g0 = gelu_erf2(f32x2_t{y0, y1}), g1 = gelu_erf2(f32x2_t{y2, y3});
                     y0 = g0.x; y1 = g0.y; y2 = g1.x; y3 = g1.y;
+                }
+                if (mx) {
+                    const unsigned sb = mx_scale_byte(max8(fmaxf(fmaxf(fabsf(y0), fabsf(y1)), fmaxf(fabsf(y2), fabsf(y3)))));
+                    const long row = mrow + it * 4;
+                    *reinterpret_cast<int*>((unsigned char*)p.out + row * p.ldo + n) = mx_pack4(y0, y1, y2, y3, mx_inv_scale(sb));
+                    sb_mine = (lane & 7) == it ? sb : sb_mine;
+                    if (it == 7) p.out_scales[(long)(mrow + (lane & 7) * 4) * (p.N >> 5) + (n >> 5)] = (unsigned char)sb_mine;
+                    continue;
                 }
                 bf16x4 hb;
                 hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
@@ -158,6 +168,12 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT]
                     *reinterpret_cast<f32x4*>((float*)p.out + (long)m * p.ldo + n) = ov;
                 } else {
                     if (EPI == 3) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
+                    if (EPI == 3 && p.out_dtype == SKIMI_FP8MX) {   // rows are valid or not per 16 lanes: the 8-lane groups are whole
+                        const unsigned sb = mx_scale_byte(max8(fmaxf(fmaxf(fabsf(y0), fabsf(y1)), fmaxf(fabsf(y2), fabsf(y3)))));
+                        *reinterpret_cast<int*>((unsigned char*)p.out + (long)m * p.ldo + n) = mx_pack4(y0, y1, y2, y3, mx_inv_scale(sb));
+                        if ((lane & 7) == 0) p.out_scales[(long)m * (p.N >> 5) + (n >> 5)] = (unsigned char)sb;
+                        continue;
+                    }
                     bf16x4 hb;
                     hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
                     *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)m * p.ldo + n) = hb;
@@ -852,6 +868,9 @@ static int epi_kind(const GemmArgs& a) {
         if (a.act == SKIMI_ACT_GELU) return 3;
         return 0;
     }
+    if (a.out_dtype == SKIMI_FP8MX && a.out_scales != nullptr && a.gamma == nullptr && a.resid == nullptr && a.bias != nullptr &&
+        a.act == SKIMI_ACT_GELU && a.N % 128 == 0)
+        return 3;   // MXFP8 result (gemm256w4_fp8_kernel only)
     if (a.out_dtype == SKIMI_F32 && a.gamma != nullptr && a.resid != nullptr && a.resid_dtype == SKIMI_F32 &&
         a.resid_rpb == 0 && a.resid_off == 0 && a.act == SKIMI_ACT_NONE)
         return 2;

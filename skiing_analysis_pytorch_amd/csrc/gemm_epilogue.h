@@ -45,6 +45,7 @@ struct GemmArgs {
     const unsigned char* a_scales;
     const unsigned char* w_scales;
     long lsa, lsw;             // bytes per scale row = Kp / 32
+    unsigned char* out_scales; // out_dtype SKIMI_FP8MX: E8M0 scales [M][N / 32] of the result (payload bytes in out, ldo = N)
 };
 
 // columns n..n+3 of row m into the records (8-byte stores; 8 lanes fill one 128-byte record)

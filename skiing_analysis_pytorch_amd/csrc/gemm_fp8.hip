@@ -39,15 +39,6 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // ---------------------------------------------------------------------------------------------------------
 // quantisation: one thread per 32-element block
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
-    // smallest e with amax * 2^-e <= 448  ->  E8M0 byte e + 127 (0 for an all-zero block)
-    if (!(amax > 0.f)) return 0u;
-    const float t = amax * (1.0f / 448.0f);
-    const unsigned u = __float_as_uint(t);
-    int e = (int)((u >> 23) & 0xFF) - 127 + ((u & 0x7FFFFF) ? 1 : 0);
-    return (unsigned)min(max(e + 127, 1), 254);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void quant_mx_kernel(const T* __restrict__ x, long ldx, long rows, int K, int Kp,
                                                        unsigned char* __restrict__ q, unsigned char* __restrict__ sc) {
@@ -85,15 +76,10 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < 32; ++j) amax = fmaxf(amax, fabsf(v[j]));
         const unsigned sb = mx_scale_byte(amax);
-        const float inv = sb ? __uint_as_float((unsigned)(254 - (int)sb) << 23) : 0.f;   // 2^-(sb - 127), exact
+        const float inv = mx_inv_scale(sb);   // 2^-(sb - 127), exact
         i32x8 out;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int w = 0;
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * j] * inv, v[4 * j + 1] * inv, w, false);
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * j + 2] * inv, v[4 * j + 3] * inv, w, true);
-            out[j] = w;
-        }
+        for (int j = 0; j < 8; ++j) out[j] = mx_pack4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3], inv);
         unsigned char* qp = q + r * Kp + k0;
         *reinterpret_cast<i32x4*>(qp) = i32x4{out[0], out[1], out[2], out[3]};
         *reinterpret_cast<i32x4*>(qp + 16) = i32x4{out[4], out[5], out[6], out[7]};
@@ -301,10 +287,13 @@ __global__ __launch_bounds__(256, TW == 2 ? 2 : 1) void gemm_fp8_kernel(const Fp
 }
 
 int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws, int M, int N, int K, const float* bias, int act,
-                    const float* gamma, const float* resid, long ldr, void* out, int out_dtype, long ldo, hipStream_t st) {
+                    const float* gamma, const float* resid, long ldr, void* out, int out_dtype, long ldo, hipStream_t st,
+                    void* out_scales) {
     SKIMI_CHECK_ARG(A && As && W && Ws && out && M > 0 && N > 0 && K > 0, "gemm_fp8: bad arguments");
     SKIMI_CHECK_ARG(N % 4 == 0 && ldo % 4 == 0 && (ldr % 4 == 0), "gemm_fp8: N and the row strides must be multiples of 4");
-    SKIMI_CHECK_ARG(out_dtype == SKIMI_F32 || out_dtype == SKIMI_BF16, "gemm_fp8: output must be fp32 or bf16");
+    SKIMI_CHECK_ARG(out_dtype == SKIMI_F32 || out_dtype == SKIMI_BF16 || out_dtype == SKIMI_FP8MX, "gemm_fp8: output must be fp32, bf16 or MXFP8");
+    SKIMI_CHECK_ARG(out_dtype != SKIMI_FP8MX || (out_scales && act == SKIMI_ACT_GELU && !gamma && !resid && bias && N % 128 == 0 && ldo == N),
+                    "gemm_fp8: MXFP8 output needs out_scales, the bias + GELU epilogue, N %% 128 == 0 and ldo == N");
     SKIMI_CHECK_ARG(act == SKIMI_ACT_NONE || act == SKIMI_ACT_GELU, "gemm_fp8: activation must be none or GELU");
     SKIMI_CHECK_ARG(!(gamma != nullptr) || resid != nullptr, "gemm_fp8: LayerScale needs the residual");
     SKIMI_CHECK_ARG(!(act == SKIMI_ACT_GELU && gamma), "gemm_fp8: GELU and LayerScale epilogues are separate");
@@ -319,7 +308,8 @@ int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws
         static const bool dyn = getenv("SKIMI_ENV_DYNAMIC") && atoi(getenv("SKIMI_ENV_DYNAMIC"));
         static int use_w4 = -1;
         if (use_w4 < 0 || dyn) use_w4 = getenv("SKIMI_FP8_W4") ? atoi(getenv("SKIMI_FP8_W4")) : 1;
-        const bool epi_ok = (out_dtype == SKIMI_BF16 && !gamma && !resid && bias) || (out_dtype == SKIMI_F32 && gamma && resid && bias);
+        const bool epi_ok = ((out_dtype == SKIMI_BF16 || out_dtype == SKIMI_FP8MX) && !gamma && !resid && bias) ||
+                            (out_dtype == SKIMI_F32 && gamma && resid && bias);
         if (use_w4 && epi_ok && M >= 2048 && N >= 512 && N % 4 == 0 && cdiv(M, 256) * cdiv(N, 256) >= 160 &&
             (((uintptr_t)A | (uintptr_t)W | (uintptr_t)As | (uintptr_t)Ws) & 15) == 0) {
             GemmArgs g;
@@ -329,6 +319,7 @@ int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws
             g.a_scales = (const unsigned char*)As; g.w_scales = (const unsigned char*)Ws; g.lsa = p.Kp / 32; g.lsw = p.Kp / 32;
             g.bias = bias; g.gamma = gamma; g.resid = resid; g.resid_dtype = SKIMI_F32; g.ldr = ldr;
             g.act = act; g.out = out; g.out_dtype = out_dtype; g.ldo = ldo; g.vec4 = 1;
+            g.out_scales = (unsigned char*)out_scales;
             const bool prof2 = prof_armed(PROF_GEMM, N);
             if (prof2) prof_before(st);
             const int rc = gemm256_fp8_launch(g, st);
@@ -336,6 +327,8 @@ int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws
             return rc;
         }
     }
+    SKIMI_CHECK_ARG(out_dtype != SKIMI_FP8MX, "gemm_fp8: MXFP8 output is served by the single-stream 256-row loop only (M >= 2048, "
+                    "N >= 512, >= 160 tiles of 256 x 256)");
     // 256 x 256 tiles where the K loop is long enough to pay for the larger epilogue and they fill most of the chip
     // (measured at M = 43968, tools/mb_fp8.py: K = 4096 -> 1207 vs 1071 TFLOP/s, K = 1024 -> 736-803 vs 828-865),
     // else 128 x 128 (two workgroups per CU).  SKIMI_FP8_TILE=128|256 forces a choice (A/B timing).

@@ -62,7 +62,11 @@ int vp3d_im2col_launch(const float* x, float* a0, int B, int L, int Cin, int k, 
 // gemm_fp8.hip: MXFP8 operands (e4m3 + E8M0 per 32 K) and the scaled-MFMA contraction
 int quant_mx_launch(const void* x, int dtype, long ldx, long rows, int K, void* q, void* scales, hipStream_t st);
 int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws, int M, int N, int K, const float* bias, int act,
-                    const float* gamma, const float* resid, long ldr, void* out, int out_dtype, long ldo, hipStream_t st);
+                    const float* gamma, const float* resid, long ldr, void* out, int out_dtype, long ldo, hipStream_t st,
+                    void* out_scales = nullptr);
+// LayerNorm straight into MXFP8 (C a multiple of 256): payload [rows][C] e4m3 + scales [rows][C / 32]
+int layernorm_mx_launch(const float* x, int64_t ldx, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                        void* payload, void* scales, hipStream_t st);
 
 // vp3d_stream.hip: the small-batch weight-streaming path of the TemporalModel (one launch per convolution)
 int vp3d_expand_launch(const float* x, const float* w, int ldw, const float* bias, float* out_f32, void* out_rec, int B, int Lin,

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
                                                             long ldx, long rows, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, void* out,
                                                             int out_dtype, long ldo, long grp_rows, long grp_stride,
-                                                            long grp_off) {
+                                                            long grp_off, unsigned char* __restrict__ out_scales = nullptr) {
     constexpr int C = NV * 256;
     const int lane = threadIdx.x & 63;
     const long orow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -106,6 +106,11 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         }
         if (out_dtype == SKIMI_F32) {
             *reinterpret_cast<float4*>((float*)out + orow * ldo + c) = make_float4(y[0], y[1], y[2], y[3]);
+        } else if (out_dtype == SKIMI_FP8MX) {
+            // MXFP8 (gemm_fp8.hip): payload [rows][C] e4m3, scales [rows][C / 32]; 8 lanes hold one 32-column block
+            const unsigned sb = mx_scale_byte(max8(fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3])))));
+            *reinterpret_cast<int*>((unsigned char*)out + orow * (long)C + c) = mx_pack4(y[0], y[1], y[2], y[3], mx_inv_scale(sb));
+            if ((lane & 7) == 0) out_scales[orow * (long)(C >> 5) + (c >> 5)] = (unsigned char)sb;
         } else if (out_dtype == SKIMI_BF16X3_REC) {
             // bf16x3 records [rows][C/32][hi 32 | lo 32] (the A operand of the LDS-DMA bf16x3 GEMM; ldo unused)
             bf16x4 h, l;
@@ -168,6 +173,27 @@ scalar_path:
     else if (nv <= 16) LN_GO(16);
     else LN_GO(32);
 #undef LN_GO
+    SKIMI_LAUNCH_CHECK();
+    return SKIMI_OK;
+}
+
+int layernorm_mx_launch(const float* x, int64_t ldx, int64_t rows, int C, const float* gamma, const float* beta, float eps,
+                        void* payload, void* scales, hipStream_t st) {
+    SKIMI_CHECK_ARG(x && payload && scales && rows > 0, "layernorm_mx: bad arguments");
+    SKIMI_CHECK_ARG(C % 256 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)payload & 3) == 0,
+                    "layernorm_mx: C must be a multiple of 256 and the rows 16-byte aligned");
+    dim3 grid((unsigned)cdiv(rows, 4)), block(256);
+#define LNM_GO(V) hipLaunchKernelGGL(layernorm_vec_kernel<V>, grid, block, 0, st, x, (const float*)nullptr, (long)ldx, (long)rows, gamma, beta, eps, payload, (int)SKIMI_FP8MX, (long)C, 0L, 0L, 0L, (unsigned char*)scales)
+    switch (C / 256) {
+        case 1: LNM_GO(1); break;
+        case 2: LNM_GO(2); break;
+        case 3: LNM_GO(3); break;
+        case 4: LNM_GO(4); break;
+        case 6: LNM_GO(6); break;
+        case 8: LNM_GO(8); break;
+        default: set_error("layernorm_mx: C = %d not supported", C); return SKIMI_ERR_ARG;
+    }
+#undef LNM_GO
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }

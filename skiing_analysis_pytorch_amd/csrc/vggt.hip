@@ -433,9 +433,17 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
     const int adt = Ctx::act_dt(prec);
     const int hidden = w.fc1.N;
     const bool fp8 = w.qkv.wq != nullptr && b.q8 != nullptr;   // SKIMI_PREC_FP8: qkv, fc1, fc2 on the MXFP8 MFMA
-    c.ln(x, nullptr, C, M, C, w.n1, eps, b.xn, adt);
+    // the quantisation rides in the producers where the shapes allow: LayerNorm writes MXFP8 directly (C % 256 == 0), and
+    // fc1's GELU epilogue writes the hidden activation as MXFP8 (large launches on the single-stream loop)
+    const bool ln_mx = fp8 && C % 256 == 0;
+    const bool hid_mx = fp8 && hidden % 128 == 0 && M >= 2048 && hidden >= 512 && cdiv(M, 256) * cdiv(hidden, 256) >= 160;
+    if (ln_mx) {
+        if (!c.rc && !c.dry()) c.rc = layernorm_mx_launch(x, C, M, C, w.n1.g, w.n1.b, eps, b.q8, b.q8s, c.st);
+    } else {
+        c.ln(x, nullptr, C, M, C, w.n1, eps, b.xn, adt);
+    }
     if (fp8) {
-        if (!c.rc && !c.dry()) c.rc = quant_mx_launch(b.xn, SKIMI_BF16, C, M, C, b.q8, b.q8s, c.st);
+        if (!ln_mx && !c.rc && !c.dry()) c.rc = quant_mx_launch(b.xn, SKIMI_BF16, C, M, C, b.q8, b.q8s, c.st);
         if (!c.rc && !c.dry())
             c.rc = gemm_fp8_launch(b.q8, b.q8s, w.qkv.wq, w.qkv.wq_scales, M, 3 * C, C, w.qkv.b, SKIMI_ACT_NONE, nullptr, nullptr, 0,
                                    b.qkv, SKIMI_BF16, 3 * C, c.st);
@@ -461,15 +469,31 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
         d.gamma = w.ls1; d.resid = x; d.ldr = C;
         c.gemm(d);
     }
-    c.ln(x, nullptr, C, M, C, w.n2, eps, b.xn, adt);
+    if (ln_mx) {
+        if (!c.rc && !c.dry()) c.rc = layernorm_mx_launch(x, C, M, C, w.n2.g, w.n2.b, eps, b.q8, b.q8s, c.st);
+    } else {
+        c.ln(x, nullptr, C, M, C, w.n2, eps, b.xn, adt);
+    }
     if (fp8) {
-        if (!c.rc && !c.dry()) c.rc = quant_mx_launch(b.xn, SKIMI_BF16, C, M, C, b.q8, b.q8s, c.st);
+        if (!ln_mx && !c.rc && !c.dry()) c.rc = quant_mx_launch(b.xn, SKIMI_BF16, C, M, C, b.q8, b.q8s, c.st);
+        // b.hid (M x hidden bf16 = 2 bytes per element) holds the MXFP8 hidden activation: payload M x hidden bytes,
+        // then its scales
+        unsigned char* hq = (unsigned char*)b.hid;
+        unsigned char* hs = hq + (size_t)M * hidden;
+        if (hid_mx) {
+            if (!c.rc && !c.dry())
+                c.rc = gemm_fp8_launch(b.q8, b.q8s, w.fc1.wq, w.fc1.wq_scales, M, hidden, C, w.fc1.b, SKIMI_ACT_GELU, nullptr, nullptr, 0,
+                                       hq, SKIMI_FP8MX, hidden, c.st, hs);
+        } else {
+            if (!c.rc && !c.dry())
+                c.rc = gemm_fp8_launch(b.q8, b.q8s, w.fc1.wq, w.fc1.wq_scales, M, hidden, C, w.fc1.b, SKIMI_ACT_GELU, nullptr, nullptr, 0,
+                                       b.hid, SKIMI_BF16, hidden, c.st);
+            if (!c.rc && !c.dry()) c.rc = quant_mx_launch(b.hid, SKIMI_BF16, hidden, M, hidden, b.q8, b.q8s, c.st);
+            hq = (unsigned char*)b.q8;
+            hs = (unsigned char*)b.q8s;
+        }
         if (!c.rc && !c.dry())
-            c.rc = gemm_fp8_launch(b.q8, b.q8s, w.fc1.wq, w.fc1.wq_scales, M, hidden, C, w.fc1.b, SKIMI_ACT_GELU, nullptr, nullptr, 0,
-                                   b.hid, SKIMI_BF16, hidden, c.st);
-        if (!c.rc && !c.dry()) c.rc = quant_mx_launch(b.hid, SKIMI_BF16, hidden, M, hidden, b.q8, b.q8s, c.st);
-        if (!c.rc && !c.dry())
-            c.rc = gemm_fp8_launch(b.q8, b.q8s, w.fc2.wq, w.fc2.wq_scales, M, C, hidden, w.fc2.b, SKIMI_ACT_NONE, w.ls2, x, C, x,
+            c.rc = gemm_fp8_launch(hq, hs, w.fc2.wq, w.fc2.wq_scales, M, C, hidden, w.fc2.b, SKIMI_ACT_NONE, w.ls2, x, C, x,
                                    SKIMI_F32, C, c.st);
         return;
     }

@@ -193,13 +193,33 @@ def quant_mx(x: torch.Tensor):
     return q, s
 
 
-def gemm_fp8(a_q, a_s, w_q, w_s, K, *, bias=None, act=ACT_NONE, gamma=None, resid=None, out=None, out_dtype=torch.float32):
-    """out[m][n] = epilogue(sum_k A[m][k] W[n][k]) on the MXFP8 MFMA; operands from `quant_mx`."""
+def layernorm_mx(x, gamma, beta, eps=1e-5):
+    """LayerNorm of fp32 rows [rows, C] written directly as an MXFP8 operand (payload, scales) -- `quant_mx(layernorm(x))`
+    in one pass (C % 256 == 0)."""
+    _require_cuda(x, gamma, beta)
+    rows, Cc = x.shape
+    q = torch.empty((rows, Cc), dtype=torch.uint8, device=x.device)
+    s = torch.empty((rows, Cc // 32), dtype=torch.uint8, device=x.device)
+    check(lib().skimi_layernorm_mx(ptr(x), x.stride(0), rows, Cc, ptr(gamma), ptr(beta), eps, ptr(q), ptr(s),
+                                   _lib.current_stream()), "skimi_layernorm_mx")
+    return q, s
+
+
+def gemm_fp8(a_q, a_s, w_q, w_s, K, *, bias=None, act=ACT_NONE, gamma=None, resid=None, out=None, out_dtype=torch.float32,
+             out_mx=False):
+    """out[m][n] = epilogue(sum_k A[m][k] W[n][k]) on the MXFP8 MFMA; operands from `quant_mx`.
+    out_mx: return (payload uint8 [M, N], scales uint8 [M, N / 32]) -- the result directly as the next gemm_fp8's operand."""
     _require_cuda(a_q, a_s, w_q, w_s, bias, gamma, resid, out)
     M, N = a_q.shape[0], w_q.shape[0]
+    if out_mx:
+        q = torch.empty((M, N), dtype=torch.uint8, device=a_q.device)
+        sc = torch.empty((M, N // 32), dtype=torch.uint8, device=a_q.device)
+        check(lib().skimi_gemm_fp8(ptr(a_q), ptr(a_s), ptr(w_q), ptr(w_s), M, N, K, ptr(bias), act, None, None, 0, ptr(q),
+                                   _lib.FP8MX, N, ptr(sc), _lib.current_stream()), "skimi_gemm_fp8")
+        return q, sc
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a_q.device)
     check(lib().skimi_gemm_fp8(ptr(a_q), ptr(a_s), ptr(w_q), ptr(w_s), M, N, K, ptr(bias), act, ptr(gamma), ptr(resid),
-                               resid.stride(0) if resid is not None else 0, ptr(out), _dt(out), out.stride(0),
+                               resid.stride(0) if resid is not None else 0, ptr(out), _dt(out), out.stride(0), None,
                                _lib.current_stream()), "skimi_gemm_fp8")
     return out

@@ -70,6 +70,63 @@ def test_gemm_fp8_matches_dequantised_product(M, N, K):
     assert rel < 5e-2, rel
 
 
+@pytest.mark.parametrize("rows,C", [(4099, 1024), (37, 256), (513, 768), (64, 2048)])
+def test_layernorm_mx_equals_quantised_layernorm(rows, C):
+    """LayerNorm -> MXFP8 in one kernel writes the bytes skimi_quant_mx makes of the same kernel's fp32 result (the
+    arithmetic before the quantisation is the same instruction sequence), and those follow the NumPy restatement."""
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn((rows, C), generator=g) * (1 + 5 * torch.rand((rows, 1), generator=g)) + torch.randn((rows, 1), generator=g)).cuda()
+    x[1] = 0.0                                     # constant row: LayerNorm gives beta
+    gamma = (1 + 0.2 * torch.randn((C,), generator=g)).cuda()
+    beta = (0.1 * torch.randn((C,), generator=g)).cuda()
+    beta[32:64] = 0.0                              # an all-zero block on the constant row
+    gamma[32:64] *= 1.0
+    q, s = ops.layernorm_mx(x, gamma, beta, 1e-5)
+    y = ops.layernorm(x, gamma, beta, 1e-5)
+    q2, s2 = ops.quant_mx(y)
+    assert torch.equal(s, s2) and torch.equal(q, q2)
+    qr, sr = mx.mx_quantize(y.cpu().numpy())
+    assert np.array_equal(s.cpu().numpy(), sr) and np.array_equal(q.cpu().numpy(), qr)
+    assert s[1, 1].item() == 0 and not q[1, 32:64].any()
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 4096, 1024), (4100, 2560, 640), (4096, 4096, 128)])
+def test_gemm_fp8_mx_output(M, N, K):
+    """fc1's epilogue writes GELU(. + bias) as the next GEMM's MXFP8 operand: against the NumPy quantisation of the
+    float64 result.  The fp32 accumulator differs from float64 by ~1e-6 relative, so a value within that of a rounding
+    boundary of e4m3 (or a block maximum within it of a power of two) may land on the neighbouring code: the dequantised
+    results agree within one e4m3 step (2^-3 relative) on those and exactly elsewhere."""
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = torch.randn((M, K), generator=g) * (1 + 3 * torch.rand((M, 1), generator=g))
+    w = torch.randn((N, K), generator=g) / K ** 0.5
+    bias = torch.randn((N,), generator=g)
+    aq, asx = ops.quant_mx(a.cuda())
+    wq, wsx = ops.quant_mx(w.cuda())
+    ref = mx.mx_dequantize(aq.cpu().numpy(), asx.cpu().numpy()) @ mx.mx_dequantize(wq.cpu().numpy(), wsx.cpu().numpy()).T
+    r = torch.nn.functional.gelu(torch.from_numpy(ref + bias.numpy().astype(np.float64))).numpy().astype(np.float32)
+    q, s = ops.gemm_fp8(aq, asx, wq, wsx, K, bias=bias.cuda(), act=ACT_GELU, out_mx=True)
+    torch.cuda.synchronize()
+    assert q.shape == (M, N) and s.shape == (M, N // 32)
+    # the same kernel's bf16 output is the rounded fp32 value: the MX bytes must be a quantisation of something within bf16
+    # rounding of it -- and, tighter, dequantise to the oracle's quantisation of the float64 result
+    got = mx.mx_dequantize(q.cpu().numpy(), s.cpu().numpy())
+    qr, sr = mx.mx_quantize(r)
+    want = mx.mx_dequantize(qr, sr)
+    same_scale = s.cpu().numpy() == sr
+    assert same_scale.mean() > 0.999
+    blk = np.abs(r).reshape(M, N // 32, 32).max(-1)
+    step = np.repeat(np.maximum(blk, 1e-30) * 2.0 ** -2, 32, axis=1).reshape(M, N)   # > one e4m3 step at the block's top binade, either scale
+    diff = np.abs(got - want)
+    assert (diff <= step).all()
+    assert (diff == 0).mean() > 0.995
+    # and the bytes are a valid operand of the next contraction (fc2): its result is the product of their dequantisation
+    w2 = torch.randn((256, N), generator=g) / N ** 0.5
+    w2q, w2s = ops.quant_mx(w2.cuda())
+    o_f = ops.gemm_fp8(q, s, w2q, w2s, N)
+    o_r = got.astype(np.float64) @ mx.mx_dequantize(w2q.cpu().numpy(), w2s.cpu().numpy()).T
+    assert np.abs(o_f.cpu().numpy() - o_r).max() < 1e-4 * np.abs(o_r).max()
+
+
 def test_vggt_fp8_mode_against_reference(golden_dir):
     """PREC_FP8 (MXFP8 qkv / fc1 / fc2 in every block, everything else as the bf16 mode) on the tiny golden: finite,
     close to the bf16 mode, and its distance to the fp32 reference stated (fp8 operands: a few 1e-2 relative)."""

@@ -21,3 +21,22 @@ for name, N, K in (("qkv", 3072, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)
     t8 = timeit(lambda: ops.gemm_fp8(aq, asx, wq, wsx, K, bias=bias, out=out))
     t16 = timeit(lambda: ops.gemm(a, wb, prec=PREC_BF16, bias=bias, out=out, out_dtype=torch.bfloat16))
     print(f"{name}: quant {tq*1e6:7.1f} us ({(M*K*3+M*K//32)/tq/1e12:.2f} TB/s) | fp8 gemm {t8*1e6:7.1f} us = {fl/t8/1e12:6.0f} TFLOP/s | bf16 gemm {t16*1e6:7.1f} us = {fl/t16/1e12:6.0f} TFLOP/s", flush=True)
+
+# quantisation fused into the producers (round 2): LayerNorm -> MXFP8 and fc1's GELU epilogue -> MXFP8
+x = torch.randn(M, 1024, device="cuda")
+g = torch.ones(1024, device="cuda"); b = torch.zeros(1024, device="cuda")
+t_ln = timeit(lambda: ops.layernorm(x, g, b, 1e-5, out_dtype=torch.bfloat16))
+xb = ops.layernorm(x, g, b, 1e-5, out_dtype=torch.bfloat16)
+t_q = timeit(lambda: ops.quant_mx(xb))
+t_lnmx = timeit(lambda: ops.layernorm_mx(x, g, b, 1e-5))
+print(f"LayerNorm(1024): -> bf16 {t_ln*1e6:.1f} us + quant {t_q*1e6:.1f} us | -> MXFP8 {t_lnmx*1e6:.1f} us", flush=True)
+K, N = 1024, 4096
+a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+w = torch.randn(N, K, device="cuda") / K ** 0.5
+bias = torch.randn(N, device="cuda")
+aq, asx = ops.quant_mx(a); wq, wsx = ops.quant_mx(w)
+hid = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+t_b = timeit(lambda: ops.gemm_fp8(aq, asx, wq, wsx, K, bias=bias, act=ACT_GELU, out=hid))
+t_hq = timeit(lambda: ops.quant_mx(hid))
+t_m = timeit(lambda: ops.gemm_fp8(aq, asx, wq, wsx, K, bias=bias, act=ACT_GELU, out_mx=True))
+print(f"fc1 + GELU: -> bf16 {t_b*1e6:.1f} us + quant {t_hq*1e6:.1f} us | -> MXFP8 {t_m*1e6:.1f} us", flush=True)
