@@ -266,8 +266,9 @@ def main():
         assert torch.isfinite(out8["pose_enc"]).all()
         line["fp8"] = {"value": B * NS / dt8, "unit": "frames/s", "ms_per_step": dt8 * 1e3, "steps": n8,
                        "mode": "SKIMI_PREC_FP8: MXFP8 (e4m3 + E8M0 per 32 K) qkv / fc1 / fc2 of the 72 blocks on "
-                               "v_mfma_scale_f32_32x32x64_f8f6f4, activations quantised per call; attention, proj, "
-                               "LayerNorm, residual stream as the bf16 mode; heads bf16x3",
+                               "v_mfma_scale_f32_32x32x64_f8f6f4, activations quantised inside their producers (LayerNorm -> "
+                               "MXFP8, fc1's GELU epilogue -> MXFP8); attention, proj, residual stream as the bf16 mode; "
+                               "heads bf16x3",
                        "pose_enc_max_abs_diff_vs_bf16_mode": (out8["pose_enc"] - out["pose_enc"]).abs().max().item()}
         active["model"] = model
         fp8_model = m8

@@ -56,8 +56,9 @@ extern "C" {
 #define SKIMI_PREC_BF16X3 1
 /* SKIMI_PREC_FP8 (skimi_vggt_config.prec only; BASELINE config 5): as SKIMI_PREC_BF16, but the qkv / fc1 / fc2
  * Linear layers of every DINOv2 / frame / global block (vggt/vggt/layers/block.py:77-98, mlp.py:34-40,
- * attention.py:50-72) run on the MXFP8 MFMA (skimi_gemm_fp8): weights quantised once at finalize, activations
- * per call (skimi_quant_mx); attention, LayerNorm, residual stream and the heads are unchanged. */
+ * attention.py:50-72) run on the MXFP8 MFMA (skimi_gemm_fp8): weights quantised once at finalize, activations by
+ * their producers (skimi_layernorm_mx; fc1's epilogue with out_dtype SKIMI_FP8MX; skimi_quant_mx where the shape
+ * rules those out); attention, proj, the fp32 residual stream and the heads are unchanged. */
 #define SKIMI_PREC_FP8 2
 
 /* activation in the GEMM epilogue */
