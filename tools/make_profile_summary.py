@@ -49,7 +49,7 @@ if mp:
     out.append(f"- joints MPJPE vs the CPU oracle at S = 8 (bar {mp['bar']}): benchmark mode {mp['bf16_bench_mode']['mpjpe']:.3g}, parity mode {mp.get('bf16x3_parity_mode', {}).get('mpjpe', float('nan')):.3g}, fp8 mode {mp.get('fp8_mode', {}).get('mpjpe', float('nan')):.3g}")
 pm = line.get('parity_mode')
 if pm:
-    out.append(f"- parity mode (bf16x3 everywhere): {pm['value']:.2f} frames/s ({pm['ms_per_step']:.0f} ms per step, {pm['time_steps_per_call']} steps per call); fp8 mode: {line.get('fp8', {}).get('value', float('nan')):.2f} frames/s")
+    out.append(f"- parity mode (bf16x3 everywhere): {pm['value']:.2f} frames/s ({pm['ms_per_step']:.0f} ms per step of {pm.get('streams', 1)} concurrent batches x {pm['time_steps_per_call']} time steps); fp8 mode: {line.get('fp8', {}).get('value', float('nan')):.2f} frames/s")
 out.append("\nPer-shape split of the attention kernel from the same trace (grouped by grid size):\n")
 out.append("| launches / batch | grid (threads) | shape | avg us |\n|---:|---:|---|---:|")
 ga = None
