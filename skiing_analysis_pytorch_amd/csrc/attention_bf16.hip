@@ -268,8 +268,10 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
 }
 
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
-                     hipStream_t st, int q_prescaled, void* x3_scratch, size_t x3_scratch_bytes) {
+                     hipStream_t st, int q_prescaled, void* x3_scratch, size_t x3_scratch_bytes, int* out_records) {
     SKIMI_CHECK_ARG(qkv && out, "skimi_attention: null buffer");
+    const bool want_rec = out_records != nullptr && *out_records != 0;
+    if (out_records) *out_records = 0;
     AttnArgs a;
     const long C = (long)heads * head_dim;
     const size_t es = dtype == SKIMI_F32 ? 4 : 2;
@@ -295,8 +297,11 @@ int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, 
         static int use_x3 = -1;
         if (use_x3 < 0 || dyn) use_x3 = getenv("SKIMI_ATTN_X3") ? atoi(getenv("SKIMI_ATTN_X3")) : 1;
         const long tokens = (long)batch * seq;
-        if (use_x3 && head_dim == 64 && x3_scratch && x3_scratch_bytes >= attention_x3_scratch_bytes(tokens, 3 * C))
-            return attention_x3_launch(a, tokens, 3 * C, x3_scratch, x3_scratch_bytes, st);
+        if (use_x3 && head_dim == 64 && x3_scratch && x3_scratch_bytes >= attention_x3_scratch_bytes(tokens, 3 * C)) {
+            const bool rec = want_rec && ((uintptr_t)out & 127) == 0;
+            if (rec) *out_records = 1;
+            return attention_x3_launch(a, tokens, 3 * C, x3_scratch, x3_scratch_bytes, st, rec);
+        }
         return attention_f32_launch(a, st);
     }
     return attention_bf16_launch(a, st);

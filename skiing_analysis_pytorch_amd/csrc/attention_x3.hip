@@ -29,6 +29,8 @@ struct AttnX3Args {
     const float* q;                       // fp32, AttnArgs strides (elements)
     const unsigned short *khi, *klo, *vhi, *vlo;   // bf16 planes, the same element strides
     float* out;
+    unsigned short* out_rec;              // or null: the result as bf16x3 records [token][C / 32][hi 32 | lo 32] instead of fp32
+    long rec_row, rec_batch;              // ushorts per token row / per batch element
     long q_row, k_row, v_row, o_row, q_batch, k_batch, v_batch, o_batch, q_head, k_head, v_head, o_head;
     int batch, heads, seq_q, seq_k;
     float scale;
@@ -218,6 +220,38 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const AttnX3Args a, int
     const float tot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.f / tot;
     const int q = q0 + l31;
+    if (a.out_rec != nullptr) {
+        // records for the proj GEMM (no fp32 copy, no split pass).  A lane pair holds a row's 64 values as 4-element pieces
+        // alternating between its two halves; one v_permlane32_swap per value pair gives every lane 8 consecutive elements
+        // (lh = 0: the even 8-element groups, lh = 1: the odd ones), i.e. one 16-byte hi and one 16-byte lo store each.
+        unsigned short* rp = a.out_rec + (long)b * a.rec_batch + (long)q * a.rec_row + (long)head * 128;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float w[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[dt][8 * pr + j] * inv),
+                                                                    __float_as_uint(o[dt][8 * pr + 4 + j] * inv), false, false);
+                    w[j] = __uint_as_float(r[0]);
+                    w[4 + j] = __uint_as_float(r[1]);
+                }
+                bf16x8 h8, l8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned short hb = f2bf(w[j]);
+                    h8[j] = (short)hb;
+                    l8[j] = (short)f2bf(w[j] - bf2f(hb));
+                }
+                if (q < a.seq_q) {
+                    unsigned short* sp = rp + dt * 64 + 8 * (2 * pr + lh);
+                    *reinterpret_cast<bf16x8*>(sp) = h8;
+                    *reinterpret_cast<bf16x8*>(sp + 32) = l8;
+                }
+            }
+        return;
+    }
     if (q < a.seq_q) {
         float* op = a.out + (long)b * a.o_batch + (long)head * a.o_head + (long)q * a.o_row;
 #pragma unroll
@@ -233,7 +267,10 @@ size_t attention_x3_scratch_bytes(long tokens, long row_elems) { return (size_t)
 
 // a: fp32 AttnArgs (q, k, v inside ONE packed buffer of `tokens` rows x `row_elems` floats starting at a.q).
 // scratch: >= attention_x3_scratch_bytes: the hi / lo planes of that buffer.
-int attention_x3_launch(const AttnArgs& a, long tokens, long row_elems, void* scratch, size_t scratch_bytes, hipStream_t st) {
+// out_records: a.out receives bf16x3 records [tokens][heads * 64 / 32][hi 32 | lo 32] (+ 256 zero bytes behind them) instead of
+// fp32 rows -- the operand form of the proj GEMM on the LDS-DMA bf16x3 kernel (o_row = heads * 64, plain [tokens, C] output)
+int attention_x3_launch(const AttnArgs& a, long tokens, long row_elems, void* scratch, size_t scratch_bytes, hipStream_t st,
+                        bool out_records) {
     SKIMI_CHECK_ARG(a.q && a.k && a.v && a.out && scratch, "attention_x3: null buffer");
     SKIMI_CHECK_ARG(a.head_dim == 64, "attention_x3: head_dim 64 only");
     SKIMI_CHECK_ARG(scratch_bytes >= attention_x3_scratch_bytes(tokens, row_elems), "attention_x3: scratch too small");
@@ -244,16 +281,36 @@ int attention_x3_launch(const AttnArgs& a, long tokens, long row_elems, void* sc
     const float* base = (const float*)a.q;
     const long koff = (const float*)a.k - base, voff = (const float*)a.v - base;
     SKIMI_CHECK_ARG(koff >= 0 && voff >= 0 && koff < row_elems && voff < row_elems, "attention_x3: q, k, v must share one packed buffer");
+    // only k and v are read as planes (q is split in registers): when they are the tail of the packed rows ([q | k | v]),
+    // the planes hold just those columns
+    const long s0 = koff < voff ? koff : voff;
+    const bool tail = a.k_row == row_elems && a.v_row == row_elems && a.k_batch % row_elems == 0 && a.v_batch % row_elems == 0 &&
+                      s0 % 8 == 0;
+    const long c0 = tail ? s0 : 0, pw = row_elems - c0;   // first column and width of the planes
     unsigned short* hi = (unsigned short*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
-    unsigned short* lo = hi + tokens * row_elems;
-    int rc = split_planes_launch(base, row_elems, tokens, (int)row_elems, hi, lo, st);
+    unsigned short* lo = hi + tokens * pw;
+    int rc = split_planes_launch(base + c0, row_elems, tokens, (int)pw, hi, lo, st);
     if (rc) return rc;
     AttnX3Args x;
-    x.q = base; x.khi = hi + koff; x.klo = lo + koff; x.vhi = hi + voff; x.vlo = lo + voff; x.out = (float*)a.out;
-    x.q_row = a.q_row; x.k_row = a.k_row; x.v_row = a.v_row; x.o_row = a.o_row;
-    x.q_batch = a.q_batch; x.k_batch = a.k_batch; x.v_batch = a.v_batch; x.o_batch = a.o_batch;
+    x.q = base; x.khi = hi + (koff - c0); x.klo = lo + (koff - c0); x.vhi = hi + (voff - c0); x.vlo = lo + (voff - c0); x.out = (float*)a.out;
+    x.q_row = a.q_row; x.k_row = tail ? pw : a.k_row; x.v_row = tail ? pw : a.v_row; x.o_row = a.o_row;
+    x.q_batch = a.q_batch; x.o_batch = a.o_batch;
+    x.k_batch = tail ? a.k_batch / row_elems * pw : a.k_batch;
+    x.v_batch = tail ? a.v_batch / row_elems * pw : a.v_batch;
     x.q_head = a.q_head; x.k_head = a.k_head; x.v_head = a.v_head; x.o_head = a.o_head;
     x.batch = a.batch; x.heads = a.heads; x.seq_q = a.seq_q; x.seq_k = a.seq_k; x.scale = a.scale;
+    x.out_rec = nullptr; x.rec_row = 0; x.rec_batch = 0;
+    if (out_records) {
+        SKIMI_CHECK_ARG(a.o_head == 64 && a.o_row == (long)a.heads * 64 && a.o_batch == (long)a.seq_q * a.o_row && ((uintptr_t)a.out & 127) == 0,
+                        "attention_x3: records output needs a plain [tokens, heads * 64] result, 128-byte aligned");
+        x.out_rec = (unsigned short*)a.out;
+        x.rec_row = a.o_row * 2;               // 4 bytes per element: [hi 32 | lo 32] per 32-column slice
+        x.rec_batch = (long)a.seq_q * x.rec_row;
+        if (hipMemsetAsync((char*)a.out + (size_t)tokens * a.o_row * 4, 0, 256, st) != hipSuccess) {   // the zero page behind the records
+            set_error("hipMemsetAsync(attention records zero page) failed");
+            return SKIMI_ERR_HIP;
+        }
+    }
     const int nqb = (int)cdiv(a.seq_q, 128);
     const long nblk = (long)nqb * a.heads * a.batch;
     SKIMI_CHECK_ARG(nblk < (1l << 31), "attention_x3: grid too large");

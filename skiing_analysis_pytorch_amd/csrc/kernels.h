@@ -50,11 +50,13 @@ int conv_direct_n32_launch(const unsigned short* in_hi, const unsigned short* in
                            long px_stride = 0);   // 0: separate planes [.., C]; 2C: pixel records [hi C | lo C]
 void attention_q64_dispatch(const AttnArgs& a, hipStream_t st);    // attention_q64.hip: 64 queries per wave
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
-                     hipStream_t st, int q_prescaled = 0, void* x3_scratch = nullptr, size_t x3_scratch_bytes = 0);
+                     hipStream_t st, int q_prescaled = 0, void* x3_scratch = nullptr, size_t x3_scratch_bytes = 0,
+                     int* out_records = nullptr);   // in: bf16x3 records wanted in `out` (fp32 mode); out: whether they were written
 // attention_x3.hip: fp32-accurate attention (head_dim 64) on the bf16 matrix pipe, operands split hi + lo; needs
 // scratch for the hi / lo planes of the packed qkv buffer (attention_launch uses it for fp32 inputs when given)
 size_t attention_x3_scratch_bytes(long tokens, long row_elems);
-int attention_x3_launch(const AttnArgs& a, long tokens, long row_elems, void* scratch, size_t scratch_bytes, hipStream_t st);
+int attention_x3_launch(const AttnArgs& a, long tokens, long row_elems, void* scratch, size_t scratch_bytes, hipStream_t st,
+                        bool out_records = false);
 
 // VideoPose3D expand-conv im2col: x [B, L, Cin] f32 -> A0 [B*(L-k+1), Kpad] f32 (zero padded)
 int vp3d_im2col_launch(const float* x, float* a0, int B, int L, int Cin, int k, int Kpad, hipStream_t st);

@@ -437,10 +437,24 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
     // fc1's GELU epilogue writes the hidden activation as MXFP8 (large launches on the single-stream loop)
     const bool ln_mx = fp8 && C % 256 == 0;
     const bool hid_mx = fp8 && hidden % 128 == 0 && M >= 2048 && hidden >= 512 && cdiv(M, 256) * cdiv(hidden, 256) >= 160;
+    // fp32-accurate mode: a Linear whose launch takes the LDS-DMA bf16x3 kernel reads its A operand as [hi 32 | lo 32]
+    // records; where the producer can write them (LayerNorm, fc1's GELU epilogue) the fp32 copy and the split pass go
+    auto as_records = [&](skimi_gemm_desc d, void* rec, size_t rec_bytes) {
+        d.A = rec; d.a_dtype = SKIMI_BF16X3_REC;
+        d.x3_scratch = (char*)rec + rec_bytes; d.x3_scratch_bytes = 256;   // the zero page behind the records
+        return d;
+    };
+    const bool x3 = adt == SKIMI_F32 && C % 256 == 0;
+    auto d_qkv = c.desc(w.qkv, b.xn, adt, C, M, b.qkv, adt, 3 * C);
+    bool rec_qkv = false;
+    if (x3) {
+        const auto q = as_records(d_qkv, b.xn, (size_t)M * C * 4);
+        if ((rec_qkv = gemm_x3dma_eligible(&q))) d_qkv = q;
+    }
     if (ln_mx) {
         if (!c.rc && !c.dry()) c.rc = layernorm_mx_launch(x, C, M, C, w.n1.g, w.n1.b, eps, b.q8, b.q8s, c.st);
     } else {
-        c.ln(x, nullptr, C, M, C, w.n1, eps, b.xn, adt);
+        c.ln(x, nullptr, C, M, C, w.n1, eps, b.xn, rec_qkv ? SKIMI_BF16X3_REC : adt);
     }
     if (fp8) {
         if (!ln_mx && !c.rc && !c.dry()) c.rc = quant_mx_launch(b.xn, SKIMI_BF16, C, M, C, b.q8, b.q8s, c.st);
@@ -448,8 +462,7 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
             c.rc = gemm_fp8_launch(b.q8, b.q8s, w.qkv.wq, w.qkv.wq_scales, M, 3 * C, C, w.qkv.b, SKIMI_ACT_NONE, nullptr, nullptr, 0,
                                    b.qkv, SKIMI_BF16, 3 * C, c.st);
     } else {
-        auto d = c.desc(w.qkv, b.xn, adt, C, M, b.qkv, adt, 3 * C);
-        c.gemm(d);
+        c.gemm(d_qkv);
     }
     int q_scaled = 0;
     if (!c.rc && !c.dry() && (w.qn_w || rope)) {
@@ -460,19 +473,39 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
                                   c.tabs->rope_cos, c.tabs->rope_sin, c.tabs->rope_npos, c.st, q_scale,
                                   adt == SKIMI_BF16 && C / heads == 64 ? &q_scaled : nullptr);
     }
-    // fp32-accurate mode: the MLP's hidden buffer (M x hidden fp32, idle until fc1) lends the hi / lo planes of qkv
+    // fp32-accurate mode: the MLP's hidden buffer (M x hidden fp32, idle until fc1) lends the hi / lo planes of k and v; the
+    // attention kernel writes proj's operand records when proj runs on the LDS-DMA kernel
+    auto d_proj = c.desc(w.proj, b.ao, adt, C, M, x, SKIMI_F32, C);
+    d_proj.gamma = w.ls1; d_proj.resid = x; d_proj.ldr = C;
+    int ao_rec = 0;
+    if (x3 && C / heads == 64) {
+        const auto q = as_records(d_proj, b.ao, (size_t)M * C * 4);
+        ao_rec = gemm_x3dma_eligible(&q) ? 1 : 0;
+    }
     if (!c.rc && !c.dry())
         c.rc = attention_launch(b.qkv, b.ao, adt, batch, seq, heads, C / heads, c.st, q_scaled, adt == SKIMI_F32 ? b.hid : nullptr,
-                                adt == SKIMI_F32 ? (size_t)M * hidden * 4 : 0);
-    {
-        auto d = c.desc(w.proj, b.ao, adt, C, M, x, SKIMI_F32, C);
-        d.gamma = w.ls1; d.resid = x; d.ldr = C;
-        c.gemm(d);
+                                adt == SKIMI_F32 ? (size_t)M * hidden * 4 : 0, &ao_rec);
+    if (ao_rec && !c.dry()) d_proj = as_records(d_proj, b.ao, (size_t)M * C * 4);
+    c.gemm(d_proj);
+    auto d_fc1 = c.desc(w.fc1, b.xn, adt, C, M, b.hid, adt, hidden);
+    d_fc1.act = SKIMI_ACT_GELU;
+    auto d_fc2 = c.desc(w.fc2, b.hid, adt, hidden, M, x, SKIMI_F32, C);
+    d_fc2.gamma = w.ls2; d_fc2.resid = x; d_fc2.ldr = C;
+    bool rec_fc1 = false;
+    if (x3) {
+        const auto q1 = as_records(d_fc1, b.xn, (size_t)M * C * 4);
+        if ((rec_fc1 = gemm_x3dma_eligible(&q1))) d_fc1 = q1;
+        const auto q2 = as_records(d_fc2, b.hid, (size_t)M * hidden * 4);
+        if (hidden % 32 == 0 && gemm_x3dma_eligible(&q2)) {   // fc1 writes the hidden activation as fc2's records, and only so
+            d_fc2 = q2;
+            d_fc1.out = nullptr;
+            d_fc1.out_records = b.hid;
+        }
     }
     if (ln_mx) {
         if (!c.rc && !c.dry()) c.rc = layernorm_mx_launch(x, C, M, C, w.n2.g, w.n2.b, eps, b.q8, b.q8s, c.st);
     } else {
-        c.ln(x, nullptr, C, M, C, w.n2, eps, b.xn, adt);
+        c.ln(x, nullptr, C, M, C, w.n2, eps, b.xn, rec_fc1 ? SKIMI_BF16X3_REC : adt);
     }
     if (fp8) {
         if (!ln_mx && !c.rc && !c.dry()) c.rc = quant_mx_launch(b.xn, SKIMI_BF16, C, M, C, b.q8, b.q8s, c.st);
@@ -497,16 +530,8 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
                                    SKIMI_F32, C, c.st);
         return;
     }
-    {
-        auto d = c.desc(w.fc1, b.xn, adt, C, M, b.hid, adt, hidden);
-        d.act = SKIMI_ACT_GELU;
-        c.gemm(d);
-    }
-    {
-        auto d = c.desc(w.fc2, b.hid, adt, hidden, M, x, SKIMI_F32, C);
-        d.gamma = w.ls2; d.resid = x; d.ldr = C;
-        c.gemm(d);
-    }
+    c.gemm(d_fc1);
+    c.gemm(d_fc2);
 }
 
 const UvTab* find_uv(const ShapeTabs* h, int w, int hh, int C) {
@@ -769,10 +794,10 @@ void run_camera(Ctx& c, const CamW& w, const float* sf, const float* sg, int B, 
     float* t2 = (float*)c.ar.alloc((size_t)R * (D / 2) * 4);
     float* delta = (float*)c.ar.alloc((size_t)R * 9 * 4);
     BlockBufs bb;
-    bb.xn = c.ar.alloc((size_t)R * D * 4);
+    bb.xn = c.ar.alloc((size_t)R * D * 4 + 256);     // + the zero page behind bf16x3 records (run_block)
     bb.qkv = c.ar.alloc((size_t)R * 3 * D * 4);
-    bb.ao = c.ar.alloc((size_t)R * D * 4);
-    bb.hid = c.ar.alloc((size_t)R * 4 * D * 4);
+    bb.ao = c.ar.alloc((size_t)R * D * 4 + 256);
+    bb.hid = c.ar.alloc((size_t)R * 4 * D * 4 + 256);
     // camera token = token 0 of every frame of the last [frame | global] intermediate
     c.ln(sf, sg, (long)P * C, R, D, w.token_norm, 1e-5f, pose_tokens, SKIMI_F32);
     LNw none;
@@ -931,10 +956,10 @@ int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query,
     {
         const size_t mk = c.ar.mark();
         BlockBufs bb;
-        bb.xn = c.ar.alloc((size_t)M * C * es);
+        bb.xn = c.ar.alloc((size_t)M * C * es + 256);     // + the zero page behind bf16x3 records (run_block)
         bb.qkv = c.ar.alloc((size_t)M * 3 * C * es);
-        bb.ao = c.ar.alloc((size_t)M * C * es);
-        bb.hid = c.ar.alloc((size_t)M * 4 * C * es);
+        bb.ao = c.ar.alloc((size_t)M * C * es + 256);
+        bb.hid = c.ar.alloc((size_t)M * 4 * C * es + 256);
         if (cfg.prec == SKIMI_PREC_FP8) {   // MXFP8 scratch of the widest quantised activation (the MLP hidden)
             const size_t kp = align_up((size_t)4 * C, 128);
             bb.q8 = c.ar.alloc((size_t)M * kp);
