@@ -377,6 +377,12 @@ def vp3d_leg(dev, cpu=True):
         res[f"clips_{B}"] = {"us_per_call": t * 1e6, "clips_per_s": B / t, "frames_per_s": B * 243 / t,
                              "algorithmic_GB": alg / 1e9, "achieved_GBps": alg / t / 1e9,
                              "frac_of_hbm_peak": alg / t / 8e12}
+        if B > 1:
+            # a batch of clips re-uses every weight B x 243 times: the call is bound by the matrix pipe, not by HBM.
+            # 4.31 GFLOP per clip; the fp32-accurate mode issues three bf16 MFMAs per product
+            fl = 4.31e9 * B
+            res[f"clips_{B}"].update({"bound": "mfma", "algorithmic_TFLOPs": fl / t / 1e12, "mfma_issue_TFLOPs": 3 * fl / t / 1e12,
+                                      "frac_of_mfma_peak": 3 * fl / t / 2.5e15})
     # the receptive-field-243 lifter of BASELINE configs[4] (5 blocks, 67.8 MB of fp32 weights): 485 input
     # frames -> 243 output frames
     fw5 = [3, 3, 3, 3, 3]
