@@ -377,6 +377,11 @@ def vp3d_leg(dev, cpu=True):
         res[f"clips_{B}"] = {"us_per_call": t * 1e6, "clips_per_s": B / t, "frames_per_s": B * 243 / t,
                              "algorithmic_GB": alg / 1e9, "achieved_GBps": alg / t / 1e9,
                              "frac_of_hbm_peak": alg / t / 8e12}
+        if B == 1:
+            res["clips_1"]["traffic"] = vp3d_traffic()
+            res["clips_1"]["traffic_source"] = ("static: profiles/r02_vp3d_traffic.json (rocprofv3 --pmc passes of this kernel source, "
+                                                "matched by its sha256; L2 <-> fabric bytes per call: each layer's 1 MB of activations is "
+                                                "fetched once per XCD from the Infinity Cache; null when the kernel changed since)")
         if B > 1:
             # a batch of clips re-uses every weight B x 243 times: the call is bound by the matrix pipe, not by HBM.
             # 4.31 GFLOP per clip; the fp32-accurate mode issues three bf16 MFMAs per product
@@ -422,6 +427,17 @@ def vp3d_leg(dev, cpu=True):
         res["cpu_oracle"] = {"s_per_clip_with_flip_tta": tc, "cores": threads,
                              "max_abs_joint_err_vs_hip": float(abs(got - ref).max())}
     return res
+
+
+def vp3d_traffic():
+    import hashlib
+    root = Path(__file__).resolve().parent
+    try:
+        d = json.loads((root / "profiles" / "r02_vp3d_traffic.json").read_text())
+        sha = hashlib.sha256((root / "skiing_analysis_pytorch_amd" / "csrc" / "vp3d_stream.hip").read_bytes()).hexdigest()[:16]
+    except (OSError, ValueError):
+        return None
+    return d["fabric_bytes_per_call"] if d.get("kernel_sha") == sha else None
 
 
 def measured_peaks():
