@@ -286,6 +286,16 @@ __global__ __launch_bounds__(256, TW == 2 ? 2 : 1) void gemm_fp8_kernel(const Fp
     }
 }
 
+// large launches go to the single-stream 256-row loop (gemm256w4_fp8_kernel); SKIMI_FP8_W4=0 keeps them here (A/B timing)
+static bool fp8_w4_shape(int M, int N) {
+    static const bool dyn = getenv("SKIMI_ENV_DYNAMIC") && atoi(getenv("SKIMI_ENV_DYNAMIC"));
+    static int use_w4 = -1;
+    if (use_w4 < 0 || dyn) use_w4 = getenv("SKIMI_FP8_W4") ? atoi(getenv("SKIMI_FP8_W4")) : 1;
+    return use_w4 && M >= 2048 && N >= 512 && N % 4 == 0 && cdiv(M, 256) * cdiv(N, 256) >= 160;
+}
+// whether a bias + GELU launch of this shape can write its result as MXFP8 (out_dtype SKIMI_FP8MX)
+bool gemm_fp8_mx_output_ok(int M, int N) { return N % 128 == 0 && fp8_w4_shape(M, N); }
+
 int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws, int M, int N, int K, const float* bias, int act,
                     const float* gamma, const float* resid, long ldr, void* out, int out_dtype, long ldo, hipStream_t st,
                     void* out_scales) {
@@ -305,13 +315,9 @@ int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws
     // GELU -> bf16; bias, LayerScale, fp32 residual -> fp32) run on the single-stream loop of gemm256.hip
     // (gemm256w4_fp8_kernel).  SKIMI_FP8_W4=0 keeps them on this file's kernel (A/B timing).
     {
-        static const bool dyn = getenv("SKIMI_ENV_DYNAMIC") && atoi(getenv("SKIMI_ENV_DYNAMIC"));
-        static int use_w4 = -1;
-        if (use_w4 < 0 || dyn) use_w4 = getenv("SKIMI_FP8_W4") ? atoi(getenv("SKIMI_FP8_W4")) : 1;
         const bool epi_ok = ((out_dtype == SKIMI_BF16 || out_dtype == SKIMI_FP8MX) && !gamma && !resid && bias) ||
                             (out_dtype == SKIMI_F32 && gamma && resid && bias);
-        if (use_w4 && epi_ok && M >= 2048 && N >= 512 && N % 4 == 0 && cdiv(M, 256) * cdiv(N, 256) >= 160 &&
-            (((uintptr_t)A | (uintptr_t)W | (uintptr_t)As | (uintptr_t)Ws) & 15) == 0) {
+        if (epi_ok && fp8_w4_shape(M, N) && (((uintptr_t)A | (uintptr_t)W | (uintptr_t)As | (uintptr_t)Ws) & 15) == 0) {
             GemmArgs g;
             memset(&g, 0, sizeof g);
             g.M = M; g.N = N; g.K = p.Kp;

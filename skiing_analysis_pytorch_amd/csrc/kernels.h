@@ -67,6 +67,7 @@ int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws
                     const float* gamma, const float* resid, long ldr, void* out, int out_dtype, long ldo, hipStream_t st,
                     void* out_scales = nullptr);
 // LayerNorm straight into MXFP8 (C a multiple of 256): payload [rows][C] e4m3 + scales [rows][C / 32]
+bool gemm_fp8_mx_output_ok(int M, int N);   // gemm_fp8_launch accepts out_dtype SKIMI_FP8MX for this shape (bias + GELU epilogue)
 int layernorm_mx_launch(const float* x, int64_t ldx, int64_t rows, int C, const float* gamma, const float* beta, float eps,
                         void* payload, void* scales, hipStream_t st);
 

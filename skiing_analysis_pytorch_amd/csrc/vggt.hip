@@ -436,7 +436,7 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
     // the quantisation rides in the producers where the shapes allow: LayerNorm writes MXFP8 directly (C % 256 == 0), and
     // fc1's GELU epilogue writes the hidden activation as MXFP8 (large launches on the single-stream loop)
     const bool ln_mx = fp8 && C % 256 == 0;
-    const bool hid_mx = fp8 && hidden % 128 == 0 && M >= 2048 && hidden >= 512 && cdiv(M, 256) * cdiv(hidden, 256) >= 160;
+    const bool hid_mx = fp8 && gemm_fp8_mx_output_ok(M, hidden);
     // fp32-accurate mode: a Linear whose launch takes the LDS-DMA bf16x3 kernel reads its A operand as [hi 32 | lo 32]
     // records; where the producer can write them (LayerNorm, fc1's GELU epilogue) the fp32 copy and the split pass go
     auto as_records = [&](skimi_gemm_desc d, void* rec, size_t rec_bytes) {

@@ -147,3 +147,31 @@ def test_vggt_fp8_mode_against_reference(golden_dir):
     assert torch.isfinite(outs["fp8"]["depth"]).all()
     assert rel16 < 3e-2 and rel8 < 0.2 and rel8 > rel16       # fp8 is the coarser arithmetic, and it is really in use
     assert pe8 < 0.3
+
+
+def test_vggt_fp8_fused_quantisation_path(monkeypatch):
+    """The block path of SKIMI_PREC_FP8 at a size where the quantisation rides in the producers (LayerNorm -> MXFP8, fc1's
+    GELU epilogue -> MXFP8 on the 256-row loop: 8 x 1374 = 10992 token rows x hidden 1024 = 172 tiles): against the fp32 CPU
+    oracle, and against the same model with the fused path switched off (SKIMI_FP8_W4=0: separate quantisation passes of the
+    bf16 activations).  The two fp8 variants differ by the bf16 rounding in front of the quantiser only."""
+    from oracle import vggt_oracle
+    cfg = W.VGGTConfig(img_size=518, embed_dim=256, depth=2, num_heads=4, patch_embed="conv", cam_trunk_depth=1, cam_heads=4,
+                       dpt_layers=(0, 0, 1, 1), enable_depth=False, enable_point=False, enable_track=False)
+    sd = W.make_vggt_state_dict(cfg, seed=5)
+    images = W.make_images(8, 518, 518, seed=6)
+    keep = {cfg.depth - 1}
+    with torch.no_grad():
+        tok, _ = vggt_oracle.aggregator_forward({k: v.float() for k, v in sd.items()}, images.unsqueeze(0), cfg.to_dict(), keep)
+    ref = tok[cfg.depth - 1][0].numpy()
+    m = vggt.VGGT(config=cfg, prec=PREC_FP8, head_prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    fused = m(images.cuda(), want={"camera"}, return_tokens=True)["tokens_last"].cpu().numpy()
+    monkeypatch.setenv("SKIMI_FP8_W4", "0")        # re-read per launch: conftest sets SKIMI_ENV_DYNAMIC=1
+    plain = m(images.cuda(), want={"camera"}, return_tokens=True)["tokens_last"].cpu().numpy()
+    monkeypatch.delenv("SKIMI_FP8_W4")
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    print(f"tokens rel err vs oracle: fused {rel(fused.reshape(ref.shape), ref):.3e}, separate passes {rel(plain.reshape(ref.shape), ref):.3e}; "
+          f"fused vs separate {rel(fused, plain):.3e}")
+    assert np.isfinite(fused).all() and not np.array_equal(fused, plain)
+    assert rel(fused.reshape(ref.shape), ref) < 0.1 and rel(plain.reshape(ref.shape), ref) < 0.1
+    assert rel(fused, plain) < 3e-2
