@@ -150,3 +150,33 @@ def test_single_view_clip_config2(bench_shape, S_sv):
     m16.load_state_dict(s["sd"])
     o16 = infer.process_single_view_clip(m16, frames, every=30)
     assert torch.isfinite(o16["pose_enc"]).all() and (o16["pose_enc"].cpu() - ref_pe).abs().max().item() < 3e-2
+
+
+def test_bench_batch_of_four_equals_its_time_steps(bench_shape):
+    """The bench's own call shape -- B = 4 time steps x 8 views per call (M = 43 968 token rows, 2752-workgroup attention
+    launches), benchmark mode, all heads -- against the same four time steps run one per call: the time steps of a
+    batch are independent (aggregator.py:184-258 never mixes them), so any difference beyond bf16 arithmetic noise
+    (other tile shapes / split-K orders at M / 4) is a batch-indexing bug at the benchmarked size.  The S = 8 oracle
+    comparison above pins what one time step computes."""
+    s = bench_shape
+    m = vggt.VGGT(config=s["cfg"], prec=PREC_BF16, head_prec=PREC_BF16X3)
+    m.load_state_dict(s["sd"])
+    g = torch.Generator().manual_seed(77)
+    images = torch.rand((4, S, 3, IMG, IMG), generator=g).cuda()
+    queries = (torch.rand((4, NQ, 2), generator=g) * (IMG - 80) + 40).cuda()
+    want = {"camera", "depth", "point", "track"}
+    whole = m(images, query_points=queries, want=want)
+    whole = {k: v.cpu() for k, v in whole.items() if torch.is_tensor(v)}
+    for b in range(4):
+        one = m(images[b:b + 1], query_points=queries[b:b + 1], want=want)
+        for k in ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf", "track", "vis", "conf"):
+            a, r = whole[k][b:b + 1], one[k].cpu()
+            assert a.shape == r.shape, k
+            assert torch.isfinite(a).all(), k
+            err = ((a - r).abs() / (r.abs() + 1.0))
+            # M = 43 968 and M = 10 992 take different tile orders / loop variants of the bf16 GEMMs, so the tokens differ at
+            # bf16 level: observed pose_enc 2.6e-3, depth 3e-4, points 1e-3, track 1.2e-3 px-relative, vis / conf 3e-2 max and
+            # 2e-3 median; an indexing bug gives O(1)
+            print(f"step {b} {k}: max {err.max().item():.3e} median {err.median().item():.3e}")
+            tol = 0.5 if k == "track" else 5e-2
+            assert err.max().item() < tol and err.median().item() < 5e-3, (k, b, err.max().item(), err.median().item())
