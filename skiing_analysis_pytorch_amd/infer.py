@@ -172,7 +172,7 @@ class CameraHead:
         return self.reconstruct_batch([frame_id], [imgs])[0]
 
     @torch.no_grad()
-    def reconstruct_batch(self, frame_ids: Sequence[int], steps: Sequence[List[torch.Tensor]]):
+    def reconstruct_batch(self, frame_ids: Sequence[int], steps: Sequence[List[torch.Tensor]], write: Optional[Sequence[bool]] = None):
         """`reconstruct_from_frames` for several independent time steps in ONE model call (B = len(steps),
         every step S frames of one source size): the steps of a clip are independent
         (vggt/multi_view_process.py:133), and batching them is what fills the chip.  Returns one
@@ -198,7 +198,7 @@ class CameraHead:
         for b in range(B):
             R, t, C = self.extrinsic_to_RT(En[b])
             K_resized = [self.scale_intrinsics(Kn[b, i], orig_size=(oh, ow), new_size=(H, W)) for i in range(S)]
-            if self.outdir is not None:
+            if self.outdir is not None and (write is None or write[b]):
                 d = self.outdir / f"frame_{int(frame_ids[b]):04d}"
                 d.mkdir(parents=True, exist_ok=True)
                 np.savez(d / "predictions.npz", extrinsic=En[b], intrinsic=Kn[b], pose_enc=pen[b])
@@ -207,13 +207,15 @@ class CameraHead:
 
 
 def save_camera_info(out_pt_path: Path, all_frame_camera_intrinsics, all_frame_R, all_frame_t, all_frame_C,
-                     all_frame_x3d=None):
+                     all_frame_x3d=None, extra: Optional[dict] = None):
     """vggt/save.py:84-110 (NPZ with camera_intrinsics [N,C,3,3], R [N,C,3,3], t [N,C,3], C [N,C,3]);
     accepts the all_frame_x3d the reference's caller passes (multi_view_process.py:312-319)."""
     data = {"camera_intrinsics": np.stack(all_frame_camera_intrinsics, axis=0), "R": np.stack(all_frame_R, axis=0),
             "t": np.stack(all_frame_t, axis=0), "C": np.stack(all_frame_C, axis=0)}
     if all_frame_x3d is not None:
         data["x3d"] = np.stack(all_frame_x3d, axis=0)
+    if extra:
+        data.update(extra)      # build-side additions (e.g. icp_refined, x3d_smoothed); the reference's keys are untouched
     np.savez_compressed(Path(out_pt_path).with_suffix(".npz"), **data)
 
 
@@ -230,14 +232,16 @@ def _side_streams(dev, n):
 
 @torch.no_grad()
 def process_multi_view_clip(model: VGGT, frames: torch.Tensor, keypoints: torch.Tensor, steps_per_call: int = 4,
-                            want_dense: bool = False, streams: int = 1) -> Dict[str, torch.Tensor]:
+                            want_dense: bool = False, streams: int = 1, smooth: bool = False) -> Dict[str, torch.Tensor]:
     """The hot loop of process_multi_view_video (vggt/multi_view_process.py:133-309) for a clip
     already in memory: frames [T, S, 3, H, W] in [0,1] (device), keypoints [T, S, J, 2] in the
     pixels of the H x W frames.  Per time step: one S-view VGGT call -> cameras -> DLT
     triangulation of the J joints over the S views.
 
     Under torch.distributed the T time steps are split in contiguous blocks across ranks and the
-    [T, J, 3] joints (+ cameras) are re-assembled on every rank with one all-gather.
+    [T, J, 3] joints (+ cameras) are re-assembled on every rank with ONE all-gather of packed per-step
+    records (parallel.all_gather_packed).  smooth=True chains BASELINE config 4's last stage on the gathered
+    joints: `fuse.temporal_smooth_ema` (fuse/fuse.py:329-412) -> "joints3d_smoothed" [T, J, 3] float64 (host).
 
     streams > 1: the calls of this rank (chunks of steps_per_call time steps, independent of each
     other) are issued from that many host threads on as many HIP streams, so the HBM-bound phases of
@@ -298,8 +302,15 @@ def process_multi_view_clip(model: VGGT, frames: torch.Tensor, keypoints: torch.
     joints = torch.cat([r[0] for r in results])
     Es = torch.cat([r[1] for r in results])
     Ks = torch.cat([r[2] for r in results])
-    return {"joints3d": parallel.all_gather_steps(joints, T), "extrinsic": parallel.all_gather_steps(Es, T),
-            "intrinsic": parallel.all_gather_steps(Ks, T)}
+    # the path's ONE collective: joints + cameras of this rank's steps as one packed record per step
+    joints, Es, Ks = parallel.all_gather_packed([joints, Es, Ks], T)
+    out = {"joints3d": joints, "extrinsic": Es, "intrinsic": Ks}
+    if smooth:
+        # BASELINE config 4: after the gather, fuse/'s temporal smoothing over the whole clip (sequential in t,
+        # O(T J) on the host as in the reference: fuse/fuse.py:329-412); every rank holds the same result
+        from . import fuse
+        out["joints3d_smoothed"] = torch.from_numpy(fuse.temporal_smooth_ema(joints.cpu().numpy().astype(np.float64)))
+    return out
 
 
 @torch.no_grad()

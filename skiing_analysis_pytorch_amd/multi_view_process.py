@@ -26,7 +26,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from . import formats, geometry, parallel
+from . import formats, fuse, geometry, parallel
 from .infer import CameraHead, cfg_get, save_camera_info
 
 logger = logging.getLogger(__name__)
@@ -95,6 +95,9 @@ def process_multi_view_video(left_video_path: Path, left_pt_path: Path, right_vi
 
     lk, _ls, lb, _lbs, lf = formats.load_info(left_pt_path, video_file_path=left_video_path, assume_normalized=False)
     rk, _rs, rb, _rbs, rf = formats.load_info(right_pt_path, video_file_path=right_video_path, assume_normalized=False)
+    for frames_, pt_, vid_ in ((lf, left_pt_path, left_video_path), (rf, right_pt_path, right_video_path)):
+        if frames_ is None:
+            raise RuntimeError(f"{pt_} embeds no frames and {vid_} cannot be decoded here (formats.read_video_frames)")
     if cfg_get(cfg, "infer.hflip", False):       # multi_view_process.py:116-127
         W0 = lf[0].shape[1]
         rf = torch.flip(rf, [2])
@@ -113,7 +116,10 @@ def process_multi_view_video(left_video_path: Path, left_pt_path: Path, right_vi
     x3d_l, K_l, R_l, t_l, C_l = [], [], [], [], []
     for a in range(lo, hi, steps_per_call):
         idx = [min(i, T - 1) for i in range(a, min(a + steps_per_call, hi))]     # padded steps repeat the last one
-        recs = head.reconstruct_batch(idx, [[lf[i], rf[i]] for i in idx])
+        # a padded step (index >= T on the last ranks) is computed to keep the collective uniform, but does not
+        # write frame_{T-1}/predictions.npz a second time
+        write = [i < T for i in range(a, min(a + steps_per_call, hi))]
+        recs = head.reconstruct_batch(idx, [[lf[i], rf[i]] for i in idx], write=write)
         Ks, Rs, ts = [], [], []
         for i, (_E, K_res, R, t, C, wp) in zip(idx, recs):
             pl = extract_person_points(wp[0], _bbox_of(lb, i), source_size)
@@ -132,13 +138,21 @@ def process_multi_view_video(left_video_path: Path, left_pt_path: Path, right_vi
         K_l += Ks
         R_l += Rs
         t_l += ts
-    # the path's one collective: per-rank joints / cameras -> every rank (no-op on one rank)
+    # the path's ONE collective: joints + K + R + t + C of this rank's steps as one packed record per step
+    # (no-op on one rank)
     dev = head.device
-    x3d = parallel.all_gather_steps(torch.cat(x3d_l), T).cpu().numpy()
-    gather = lambda lst: parallel.all_gather_steps(torch.from_numpy(np.stack(lst)).to(dev), T).cpu().numpy()   # noqa: E731
-    Ka, Ra, ta, Ca = gather(K_l), gather(R_l), gather(t_l), gather(C_l)
+    todev = lambda lst: torch.from_numpy(np.stack(lst)).to(dev)   # noqa: E731
+    x3d, Ka, Ra, ta, Ca = (a.cpu().numpy() for a in parallel.all_gather_packed(
+        [torch.cat(x3d_l), todev(K_l), todev(R_l), todev(t_l), todev(C_l)], T))
+    # fuse/'s temporal smoothing of the gathered joints (BASELINE config 4; fuse/fuse.py:329-412)
+    x3d_smoothed = fuse.temporal_smooth_ema(x3d.astype(np.float64)) if cfg_get(cfg, "infer.smooth", True) else None
     if parallel.world()[0] == 0:
+        # icp_refined = False: the reference stores R, t and the joints AFTER its Open3D ICP update
+        # (multi_view_process.py:285-319); this build has no ICP (out of scope, "parity unpinned"), the arrays are
+        # the pre-ICP quantities under the same keys
+        logger.warning("[Run-MV] cameras / joints are written without the reference's Open3D ICP refinement (icp_refined=False)")
         save_camera_info(out_pt_path=inference_output_path / f"{subject}_multi_view_3d_info.npz",
                          all_frame_x3d=list(x3d), all_frame_camera_intrinsics=list(Ka), all_frame_R=list(Ra),
-                         all_frame_t=list(ta), all_frame_C=list(Ca))
+                         all_frame_t=list(ta), all_frame_C=list(Ca),
+                         extra={"icp_refined": np.array(False)} | ({"x3d_smoothed": x3d_smoothed} if x3d_smoothed is not None else {}))
     return out_dir

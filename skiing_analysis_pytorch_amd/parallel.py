@@ -37,3 +37,44 @@ def all_gather_steps(local: torch.Tensor, T: int) -> torch.Tensor:
     out = torch.empty((world_size * local.shape[0], *local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)
     return out[:T]
+
+
+def pack_steps(parts) -> tuple:
+    """Per-step tensors [n, ...] of any dtypes -> (one uint8 buffer [n, bytes_per_step], layout).  The record of a
+    time step is the concatenation of that step's slice of every part, so ONE collective moves joints and cameras
+    together (north_star: "an RCCL all-gather ... only to reassemble the per-frame 3D-keypoint tensor")."""
+    n = parts[0].shape[0]
+    if n == 0:
+        raise ValueError("pack_steps: no time steps (shard_range pads every rank to at least one)")
+    cols, layout = [], []
+    for p in parts:
+        if p.shape[0] != n:
+            raise ValueError("pack_steps: every part needs the same number of time steps")
+        p = p.contiguous()
+        raw = p.view(torch.uint8).reshape(n, -1)
+        layout.append((p.dtype, tuple(p.shape[1:]), raw.shape[1]))
+        cols.append(raw)
+    return torch.cat(cols, dim=1).contiguous(), layout
+
+
+def unpack_steps(buf: torch.Tensor, layout) -> list:
+    """inverse of pack_steps on a [T, bytes_per_step] uint8 buffer"""
+    out, off = [], 0
+    T = buf.shape[0]
+    for dtype, shape, nbytes in layout:
+        out.append(buf[:, off:off + nbytes].contiguous().view(dtype).reshape(T, *shape))
+        off += nbytes
+    return out
+
+
+def all_gather_packed(parts, T: int) -> list:
+    """parts: this rank's per-step tensors [T_pad/W, ...] (joints, K, R, t, C ...; any dtypes, one device) ->
+    the same list with [T, ...] on every rank, through ONE all_gather_into_tensor of the packed byte records
+    (pad dropped).  World size 1: no collective, the parts themselves (cut to T)."""
+    rank, world_size = world()
+    if world_size == 1:
+        return [p[:T] for p in parts]
+    buf, layout = pack_steps(parts)
+    out = torch.empty((world_size * buf.shape[0], buf.shape[1]), dtype=torch.uint8, device=buf.device)
+    dist.all_gather_into_tensor(out, buf)
+    return unpack_steps(out[:T], layout)
