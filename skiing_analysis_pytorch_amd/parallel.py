@@ -62,7 +62,7 @@ def unpack_steps(buf: torch.Tensor, layout) -> list:
     out, off = [], 0
     T = buf.shape[0]
     for dtype, shape, nbytes in layout:
-        out.append(buf[:, off:off + nbytes].clone().view(dtype).reshape(T, *shape))   # clone: a fresh, aligned allocation
+        out.append(buf[:, off:off + nbytes].reshape(-1).clone().view(dtype).reshape(T, *shape))   # clone: a fresh, aligned, flat allocation
         off += nbytes
     return out
 
