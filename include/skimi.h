@@ -43,6 +43,7 @@ extern "C" {
 #define SKIMI_BF16 1
 #define SKIMI_BF16X3_REC 2 /* skimi_gemm_desc.a_dtype only: A already split into [hi 32 | lo 32] records */
 #define SKIMI_FP8MX 3      /* skimi_gemm_fp8 out_dtype only: the result as MXFP8 (payload in out, E8M0 scales in out_scales) */
+#define SKIMI_F16 4        /* IEEE binary16 (operands / activations of SKIMI_PREC_F16) */
 
 /* arithmetic mode of the MFMA contractions
  *   SKIMI_PREC_BF16   : operands rounded to bf16, one v_mfma_f32_32x32x16_bf16 per
@@ -60,6 +61,15 @@ extern "C" {
  * their producers (skimi_layernorm_mx; fc1's epilogue with out_dtype SKIMI_FP8MX; skimi_quant_mx where the shape
  * rules those out); attention, proj, the fp32 residual stream and the heads are unchanged. */
 #define SKIMI_PREC_FP8 2
+/* SKIMI_PREC_F16: the Linear layers of the DINOv2 / frame / global blocks and the patch embedding
+ * (vggt/vggt/layers/block.py:77-98, mlp.py:34-40, attention.py:50-72, patch_embed.py:65-78) with fp16 operands on
+ * v_mfma_f32_32x32x16_f16, fp32 accumulate: the same matrix rate as bf16 with three more mantissa bits.  The operand
+ * rounding of the Linears is what puts bf16 outside north_star's 1e-3 on the joints (profiles/r03_precision_ablation.md);
+ * with fp16 there the joints are inside it.  LayerNorm, the attention epilogue and fc1's GELU epilogue write fp16;
+ * the attention products (QK^T, PV: they average their rounding noise over all keys) keep bf16 q, k, v, P; residual
+ * stream, LayerNorm, softmax and accumulation are fp32 as in every mode.  In skimi_gemm_desc: fp16 (or fp32, rounded
+ * to fp16 while staged) A and W, a_dtype / w_dtype SKIMI_F16 / SKIMI_F32. */
+#define SKIMI_PREC_F16 3
 
 /* activation in the GEMM epilogue */
 #define SKIMI_ACT_NONE 0
@@ -93,7 +103,7 @@ typedef struct skimi_gemm_desc {
     int32_t M, N, K;          /* out rows, out cols, contraction length (K % 8 == 0) */
     const void* A;            /* dev; [rows, lda] f32 or bf16, channels-last */
     const void* W;            /* dev; [N, ldw] f32 (BF16X3) or bf16 (BF16): nn.Linear layout */
-    int32_t a_dtype, w_dtype; /* SKIMI_F32 / SKIMI_BF16; a_dtype SKIMI_BF16X3_REC: see W_split */
+    int32_t a_dtype, w_dtype; /* SKIMI_F32 / SKIMI_BF16 (SKIMI_F16 under SKIMI_PREC_F16); a_dtype SKIMI_BF16X3_REC: see W_split */
     int64_t lda, ldw;         /* in elements */
     int32_t prec;             /* SKIMI_PREC_* */
     /* A gather: a_mode 0 = plain rows; 1 = implicit im2col of a channels-last image
@@ -127,7 +137,7 @@ typedef struct skimi_gemm_desc {
     /* store: store_mode 0 = out[row*ldo + n]; 1 = ConvTranspose2d with kernel == stride
      * (ps_s): m = (img, iy, ix) over [cN, cH, cW], n = (a*ps_s + b)*ps_C + co,
      * out[((img*cH*ps_s + iy*ps_s + a)*cW*ps_s + ix*ps_s + b)*ldo + co] */
-    void* out;                /* dev; f32 or bf16 */
+    void* out;                /* dev; f32, bf16 or fp16 */
     void* out2;               /* dev or NULL: second copy in the other dtype (same indexing, ldo2) */
     int32_t out_dtype;
     int64_t ldo, ldo2;
@@ -247,6 +257,11 @@ int skimi_qknorm_rope(void* qkv, int32_t dtype, int64_t tokens, int32_t heads,
  * dtype bf16 + head_dim 64 runs the MFMA flash kernel; f32 runs the exact fp32 kernel. */
 int skimi_attention(const void* qkv, void* out, int32_t dtype, int32_t batch, int32_t seq,
                     int32_t heads, int32_t head_dim, void* stream);
+/* The same with the output type named: out_dtype == dtype, or SKIMI_F16 with dtype SKIMI_BF16 -- the form
+ * SKIMI_PREC_F16 runs (bf16 q / k / v and probabilities, the result rows rounded once to fp16: the operand of
+ * the proj Linear, attention.py:62-64). */
+int skimi_attention_out(const void* qkv, void* out, int32_t dtype, int32_t out_dtype, int32_t batch, int32_t seq,
+                        int32_t heads, int32_t head_dim, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* VideoPose3D TemporalModel lifter  (VideoPose3D/common/model.py:79-138)     */
@@ -289,8 +304,9 @@ typedef struct skimi_vggt_config {
     int32_t track_features, track_hidden, track_corr_levels, track_corr_radius, track_iters, track_depth,
         track_heads, track_virtual;
     int32_t enable_camera, enable_depth, enable_point, enable_track;
-    /* MFMA mode of the DINOv2 + aggregator blocks and of the track head (bf16 under the
-     * reference's autocast, infer.py:78-84; vggt.py:85 runs the track head inside it) */
+    /* MFMA mode of the patch embedding and the DINOv2 / frame / global blocks: SKIMI_PREC_BF16 (the reference's
+     * autocast, infer.py:78-84), SKIMI_PREC_F16 (fp16 operands: the joints stay within 1e-3 of the fp32 path),
+     * SKIMI_PREC_BF16X3 (fp32-accurate) or SKIMI_PREC_FP8 */
     int32_t prec;
     /* MFMA mode of the camera/DPT heads, which the reference runs in fp32
      * (torch.cuda.amp.autocast(enabled=False), vggt.py:65): BF16X3 = faithful, BF16 = fast */

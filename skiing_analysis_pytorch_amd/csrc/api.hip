@@ -19,6 +19,23 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int lds_opt_in(std::atomic<unsigned>& done, const void* kernel, int bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        set_error("hipGetDevice failed (%s)", what);
+        return SKIMI_ERR_HIP;
+    }
+    const unsigned bit = 1u << (dev & 31);
+    if (done.load(std::memory_order_acquire) & bit) return SKIMI_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(%s, %d bytes of LDS) failed: %s", what, bytes, hipGetErrorString(e));
+        return SKIMI_ERR_HIP;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return SKIMI_OK;
+}
+
 struct ProfState {
     int kind = PROF_NONE;
     long min_key = 0;
@@ -176,6 +193,14 @@ int skimi_qknorm_rope(void* qkv, int32_t dtype, int64_t tokens, int32_t heads, c
 int skimi_attention(const void* qkv, void* out, int32_t dtype, int32_t batch, int32_t seq,
                     int32_t heads, int32_t head_dim, void* stream) {
     return attention_launch(qkv, out, dtype, batch, seq, heads, head_dim, (hipStream_t)stream);
+}
+
+int skimi_attention_out(const void* qkv, void* out, int32_t dtype, int32_t out_dtype, int32_t batch, int32_t seq,
+                        int32_t heads, int32_t head_dim, void* stream) {
+    SKIMI_CHECK_ARG(out_dtype == dtype || (dtype == SKIMI_BF16 && out_dtype == SKIMI_F16),
+                    "skimi_attention_out: out_dtype is dtype, or SKIMI_F16 for bf16 q / k / v (got %d -> %d)", dtype, out_dtype);
+    return attention_launch(qkv, out, dtype, batch, seq, heads, head_dim, (hipStream_t)stream, 0, nullptr, 0, nullptr,
+                            out_dtype == SKIMI_F16 && dtype == SKIMI_BF16);
 }
 
 }  // extern "C"

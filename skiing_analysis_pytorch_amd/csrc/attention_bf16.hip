@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const AttnArgs a, int
             for (int g = 0; g < 4; ++g) {
                 bf16x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (short)f2bf(o[dt][4 * g + j] * inv);
+                for (int j = 0; j < 4; ++j) v[j] = (short)f2x16(o[dt][4 * g + j] * inv, a.out_f16 != 0);
                 *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g + 4 * lh) = v;
             }
     }
@@ -268,7 +268,7 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
 }
 
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
-                     hipStream_t st, int q_prescaled, void* x3_scratch, size_t x3_scratch_bytes, int* out_records) {
+                     hipStream_t st, int q_prescaled, void* x3_scratch, size_t x3_scratch_bytes, int* out_records, int out_f16) {
     SKIMI_CHECK_ARG(qkv && out, "skimi_attention: null buffer");
     const bool want_rec = out_records != nullptr && *out_records != 0;
     if (out_records) *out_records = 0;
@@ -290,6 +290,7 @@ int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, 
     a.head_dim = head_dim;
     a.scale = 1.0f / sqrtf((float)head_dim);
     a.q_prescaled = dtype == SKIMI_F32 ? 0 : q_prescaled;
+    a.out_f16 = dtype == SKIMI_F32 ? 0 : out_f16;
     if (dtype == SKIMI_F32) {
         // fp32-accurate mode: the bf16x3 kernel when the caller lends scratch for the hi / lo planes (SKIMI_ATTN_X3=0: the
         // exact-fp32 MFMA kernel, A/B timing and a cross-check in the tests)

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
                 for (int g = 0; g < 4; ++g) {
                     bf16x4 v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (short)f2bf(o[qi][dt][4 * g + j] * inv);
+                    for (int j = 0; j < 4; ++j) v[j] = (short)f2x16(o[qi][dt][4 * g + j] * inv, a.out_f16 != 0);
                     *reinterpret_cast<bf16x4*>(op + dt * 32 + 8 * g + 4 * lh) = v;
                 }
         }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/skimi.h"
@@ -47,6 +48,16 @@ bool prof_armed(int kind, long size_key);
 void prof_before(hipStream_t st);
 void prof_after(hipStream_t st, double flops, double bytes);
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS, once per (kernel, device): `done` is that kernel's own static
+// mask (bit = device ordinal).  Thread-safe: two racing first calls both set the attribute, which is idempotent.
+int lds_opt_in(std::atomic<unsigned>& done, const void* kernel, int bytes, const char* what);
+#define SKIMI_LDS_OPT_IN(KERNEL, BYTES, WHAT)                                                            \
+    do {                                                                                                 \
+        static std::atomic<unsigned> done_{0};                                                           \
+        const int rc_ = ::skimi::lds_opt_in(done_, reinterpret_cast<const void*>(KERNEL), (int)(BYTES), WHAT); \
+        if (rc_ != SKIMI_OK) return rc_;                                                                 \
+    } while (0)
+
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
@@ -63,6 +74,27 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
 }
 __device__ __forceinline__ float bf2f(unsigned short b) {
     return __builtin_bit_cast(float, ((unsigned int)b) << 16);
+}
+// fp32 -> fp16, round to nearest even (v_cvt_f16_f32; NOT the round-toward-zero v_cvt_pkrtz), and back
+__device__ __forceinline__ unsigned short f2h(float x) {
+    _Float16 h = (_Float16)x;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float h2f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+// fp32 -> the 16-bit operand format of a contraction: fp16 (SKIMI_F16) or bf16.  Both conversions are computed and
+// one is selected (no branch: a branch in an epilogue costs a vmcnt(0) per store on gfx9)
+__device__ __forceinline__ unsigned short f2x16(float x, bool f16) {
+    const unsigned short a = f2h(x), b = f2bf(x);
+    return f16 ? a : b;
+}
+// one k-step of a 32x32 output tile on 16-bit operands: fp16 (F16) or bf16 fragments, fp32 accumulate
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 // MXFP8 (gemm_fp8.hip): E8M0 byte of a 32-element block = smallest power of two with amax / scale <= 448 (0: all zero),
 // and its inverse as an exact power of two

@@ -210,16 +210,7 @@ int conv_direct_n32_launch(const unsigned short* in_hi, const unsigned short* in
     SKIMI_CHECK_ARG(C % 32 == 0 && C >= 32 && F > 0 && H > 0 && W > 0, "conv_direct: bad shape");
     SKIMI_CHECK_ARG((((uintptr_t)in_hi | (uintptr_t)in_lo | (uintptr_t)w_packed) & 15) == 0, "conv_direct: 16-B alignment");
     constexpr size_t lds = 2ull * CD_BUF;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_n32_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(conv_direct) failed: %s", hipGetErrorString(e));
-            return SKIMI_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    SKIMI_LDS_OPT_IN(conv_direct_n32_kernel, lds, "conv_direct");
     ConvDirectArgs a;
     a.in_hi = in_hi; a.in_lo = in_lo; a.w = w_packed; a.bias = bias; a.out = out;
     a.F = F; a.H = H; a.W = W; a.C = C; a.relu = relu;

@@ -68,15 +68,24 @@ __device__ __forceinline__ void stage_split(const Stage<unsigned short>& s, bf16
     hi = s.v;
     lo = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
 }
+template <bool F16>
 __device__ __forceinline__ bf16x8 stage_round(const Stage<float>& s) {
     bf16x8 r;
-    r[0] = (short)f2bf(s.a.x); r[1] = (short)f2bf(s.a.y); r[2] = (short)f2bf(s.a.z); r[3] = (short)f2bf(s.a.w);
-    r[4] = (short)f2bf(s.b.x); r[5] = (short)f2bf(s.b.y); r[6] = (short)f2bf(s.b.z); r[7] = (short)f2bf(s.b.w);
+    if constexpr (F16) {
+        r[0] = (short)f2h(s.a.x); r[1] = (short)f2h(s.a.y); r[2] = (short)f2h(s.a.z); r[3] = (short)f2h(s.a.w);
+        r[4] = (short)f2h(s.b.x); r[5] = (short)f2h(s.b.y); r[6] = (short)f2h(s.b.z); r[7] = (short)f2h(s.b.w);
+    } else {
+        r[0] = (short)f2bf(s.a.x); r[1] = (short)f2bf(s.a.y); r[2] = (short)f2bf(s.a.z); r[3] = (short)f2bf(s.a.w);
+        r[4] = (short)f2bf(s.b.x); r[5] = (short)f2bf(s.b.y); r[6] = (short)f2bf(s.b.z); r[7] = (short)f2bf(s.b.w);
+    }
     return r;
 }
-__device__ __forceinline__ bf16x8 stage_round(const Stage<unsigned short>& s) { return s.v; }
+template <bool F16>
+__device__ __forceinline__ bf16x8 stage_round(const Stage<unsigned short>& s) { return s.v; }   // 16-bit operands pass through
 
-template <int BM, int BN, int BK, int NSPLIT, typename TA, typename TW, int DEPTH>
+// F16: the 16-bit operands are fp16 (SKIMI_PREC_F16: fp32 inputs are rounded to fp16 while staged) and the matrix
+// instruction is v_mfma_f32_32x32x16_f16; otherwise bf16.  NSPLIT 3 (bf16x3) is bf16 only.
+template <int BM, int BN, int BK, int NSPLIT, typename TA, typename TW, int DEPTH, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int CPR = BK / 8;        // 16-B chunks per LDS row
     constexpr int RB = BK * 2;         // LDS row bytes
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 *reinterpret_cast<bf16x8*>(base + o) = hi;                                              \
                 *reinterpret_cast<bf16x8*>(base + A_PLANE + o) = lo;                                    \
             } else {                                                                                    \
-                *reinterpret_cast<bf16x8*>(base + o) = stage_round(sa[SET][i]);                         \
+                *reinterpret_cast<bf16x8*>(base + o) = stage_round<F16>(sa[SET][i]);                         \
             }                                                                                           \
         }                                                                                               \
         char* wbw = base + NPL * A_PLANE;                                                               \
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 *reinterpret_cast<bf16x8*>(wbw + o) = hi;                                               \
                 *reinterpret_cast<bf16x8*>(wbw + W_PLANE + o) = lo;                                     \
             } else {                                                                                    \
-                *reinterpret_cast<bf16x8*>(wbw + o) = stage_round(sw[SET][i]);                          \
+                *reinterpret_cast<bf16x8*>(wbw + o) = stage_round<F16>(sw[SET][i]);                          \
             }                                                                                           \
         }                                                                                               \
     }
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                                     acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], w_hi[jj], acc[i][jj], 0, 0, 0);
                                     acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], w_lo[jj], acc[i][jj], 0, 0, 0);
                                 }
-                                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], w_hi[jj], acc[i][jj], 0, 0, 0);
+                                acc[i][jj] = mfma_32x32x16<F16>(a_hi[i], w_hi[jj], acc[i][jj]);
                             }
                     }
                 }
@@ -377,23 +386,14 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue(const GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int BK, int NSPLIT, typename TA, typename TW>
+template <int BM, int BN, int BK, int NSPLIT, typename TA, typename TW, bool F16 = false>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
     // 64 x 64 tiles serve the skinny, load-latency-bound shapes: prefetch 4 K-tiles deep
     constexpr int DEPTH = (BM == 64 && BN == 64) ? 4 : 1;
     constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
     constexpr size_t lds = 2ull * NPL * (BM + BN) * BK * 2;
-    auto kfn = gemm_kernel<BM, BN, BK, NSPLIT, TA, TW, DEPTH>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return SKIMI_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    auto kfn = gemm_kernel<BM, BN, BK, NSPLIT, TA, TW, DEPTH, F16>;
+    SKIMI_LDS_OPT_IN(kfn, lds, "gemm");
     dim3 grid(a.ntm * a.ntn, a.splitk);
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
     SKIMI_LAUNCH_CHECK();
@@ -416,9 +416,16 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     }
     SKIMI_CHECK_ARG(d->lda % 4 == 0 && d->ldw % 8 == 0 && d->lda >= 0,
                     "skimi_gemm: lda/ldw must keep 16-B alignment (lda=%ld ldw=%ld)", (long)d->lda, (long)d->ldw);
-    SKIMI_CHECK_ARG(!(d->a_dtype == SKIMI_BF16 && d->lda % 8 != 0), "skimi_gemm: bf16 lda must be a multiple of 8");
-    SKIMI_CHECK_ARG(d->prec == SKIMI_PREC_BF16 || d->prec == SKIMI_PREC_BF16X3, "skimi_gemm: bad prec %d", d->prec);
-    const int BK = d->prec == SKIMI_PREC_BF16 ? 64 : 32;
+    SKIMI_CHECK_ARG(!((d->a_dtype == SKIMI_BF16 || d->a_dtype == SKIMI_F16) && d->lda % 8 != 0), "skimi_gemm: 16-bit lda must be a multiple of 8");
+    SKIMI_CHECK_ARG(d->prec == SKIMI_PREC_BF16 || d->prec == SKIMI_PREC_BF16X3 || d->prec == SKIMI_PREC_F16, "skimi_gemm: bad prec %d", d->prec);
+    {   // 16-bit operands carry the format of the mode: bf16 under SKIMI_PREC_BF16 / BF16X3, fp16 under SKIMI_PREC_F16
+        const int bad = d->prec == SKIMI_PREC_F16 ? SKIMI_BF16 : SKIMI_F16;
+        SKIMI_CHECK_ARG(d->a_dtype != bad && d->w_dtype != bad, "skimi_gemm: prec %d does not take %s operands", d->prec,
+                        bad == SKIMI_BF16 ? "bf16" : "fp16");
+        SKIMI_CHECK_ARG(d->prec == SKIMI_PREC_F16 || (d->out_dtype != SKIMI_F16), "skimi_gemm: fp16 output belongs to SKIMI_PREC_F16");
+        SKIMI_CHECK_ARG(d->out_dtype == SKIMI_F32 || d->out_dtype == SKIMI_BF16 || d->out_dtype == SKIMI_F16, "skimi_gemm: bad out_dtype %d", d->out_dtype);
+    }
+    const int BK = d->prec == SKIMI_PREC_BF16X3 ? 32 : 64;
     if (d->a_mode != 0) {
         SKIMI_CHECK_ARG(d->cC % BK == 0, "skimi_gemm: conv gather needs cC %% %d == 0 (cC=%d)", BK, d->cC);
         SKIMI_CHECK_ARG(d->a_mode != 2 || BK == 32, "skimi_gemm: slice-major conv weights (a_mode 2) need a K-tile of 32 (fp32-accurate mode)");
@@ -453,6 +460,7 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     a.out_rec = (unsigned short*)d->out_records;
     a.rec_row = (long)(d->N / 32) * 64;
     a.partial = nullptr;
+    a.f16 = d->prec == SKIMI_PREC_F16;
     {
         auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
         const bool out_ok = d->out_dtype == SKIMI_F32 ? al16(d->out) : (((uintptr_t)d->out & 7) == 0);
@@ -533,7 +541,25 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     if (prof) prof_before(st);
     const bool af = d->a_dtype == SKIMI_F32, wf = d->w_dtype == SKIMI_F32;
 #define SKIMI_GO(BM_, BK_, NS_, TA_, TW_) rc = launch_cfg<BM_, BM_, BK_, NS_, TA_, TW_>(a, st)
-    if (BN == 64 && BM == 128) {
+#define SKIMI_GO16(BM_, BN_, TA_, TW_) rc = launch_cfg<BM_, BN_, 64, 1, TA_, TW_, true>(a, st)
+    if (d->prec == SKIMI_PREC_F16) {
+        if (BN == 64 && BM == 128) {
+            if (af && wf) SKIMI_GO16(128, 64, float, float);
+            else if (af) SKIMI_GO16(128, 64, float, unsigned short);
+            else if (wf) SKIMI_GO16(128, 64, unsigned short, float);
+            else SKIMI_GO16(128, 64, unsigned short, unsigned short);
+        } else if (BM == 128) {
+            if (af && wf) SKIMI_GO16(128, 128, float, float);
+            else if (af) SKIMI_GO16(128, 128, float, unsigned short);
+            else if (wf) SKIMI_GO16(128, 128, unsigned short, float);
+            else SKIMI_GO16(128, 128, unsigned short, unsigned short);
+        } else {
+            if (af && wf) SKIMI_GO16(64, 64, float, float);
+            else if (af) SKIMI_GO16(64, 64, float, unsigned short);
+            else if (wf) SKIMI_GO16(64, 64, unsigned short, float);
+            else SKIMI_GO16(64, 64, unsigned short, unsigned short);
+        }
+    } else if (BN == 64 && BM == 128) {
         if (d->prec == SKIMI_PREC_BF16) {
             if (af && wf) rc = launch_cfg<128, 64, 64, 1, float, float>(a, st);
             else if (af) rc = launch_cfg<128, 64, 64, 1, float, unsigned short>(a, st);
@@ -567,6 +593,7 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
         }
     }
 #undef SKIMI_GO
+#undef SKIMI_GO16
     if (prof) {
         const double ea = af ? 4.0 : 2.0, ew = wf ? 4.0 : 2.0, eo = d->out_dtype == SKIMI_F32 ? 4.0 : 2.0;
         prof_after(st, 2.0 * d->M * (double)d->N * d->K,

@@ -57,7 +57,20 @@ __device__ __forceinline__ void tile_coords256(const GemmArgs& p, int& tm, int& 
 // The residual epilogue (EPI 2) is a chain of global round trips per pass (residual load -> add ->
 // store, and loads wait behind older stores in vmcnt), so the residual rows of the next PF passes
 // are requested ahead: PF passes x 8 float4 = 32 PF registers.
-template <int MT, int EPI, int PF = 2>
+// H16: the 16-bit rows of EPI 1 / 3 are fp16 instead of bf16 (compile time: a runtime select would double the
+// conversions of an epilogue whose VALU time is exposed)
+template <bool H16>
+__device__ __forceinline__ bf16x4 pack4_16(float y0, float y1, float y2, float y3) {
+    bf16x4 hb;
+    if constexpr (H16) {
+        hb[0] = (short)f2h(y0); hb[1] = (short)f2h(y1); hb[2] = (short)f2h(y2); hb[3] = (short)f2h(y3);
+    } else {
+        hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
+    }
+    return hb;
+}
+
+template <int MT, int EPI, int PF = 2, bool H16 = false>
 __device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT][2], char* smem, int wave, int lane,
                                             int wr, int wc, int m0, int n0) {
     const int l31 = lane & 31, lh = lane >> 5;
@@ -142,9 +155,7 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT]
                     if (it == 7) p.out_scales[(long)(mrow + (lane & 7) * 4) * (p.N >> 5) + (n >> 5)] = (unsigned char)sb_mine;
                     continue;
                 }
-                bf16x4 hb;
-                hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
-                *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)(mrow + it * 4) * p.ldo + n) = hb;
+                *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)(mrow + it * 4) * p.ldo + n) = pack4_16<H16>(y0, y1, y2, y3);
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);   // slab reads retired before the next pass overwrites it
         }
@@ -174,9 +185,7 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT]
                         if ((lane & 7) == 0) p.out_scales[(long)m * (p.N >> 5) + (n >> 5)] = (unsigned char)sb;
                         continue;
                     }
-                    bf16x4 hb;
-                    hb[0] = (short)f2bf(y0); hb[1] = (short)f2bf(y1); hb[2] = (short)f2bf(y2); hb[3] = (short)f2bf(y3);
-                    *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)m * p.ldo + n) = hb;
+                    *reinterpret_cast<bf16x4*>((unsigned short*)p.out + (long)m * p.ldo + n) = pack4_16<H16>(y0, y1, y2, y3);
                 }
             }
         } else {
@@ -203,7 +212,9 @@ __device__ __forceinline__ void epilogue256(const GemmArgs& p, f32x16 (&acc)[MT]
 
 // EPI: 0 = generic epilogue (runtime flags); 1 = bias -> bf16 rows (qkv); 3 = bias, GELU -> bf16
 //      rows (fc1); 2 = bias, LayerScale, fp32 residual -> fp32 rows, plain row map (proj, fc2)
-template <int MT, int EPI>   // M tiles of 32 rows per wave: BM = 64 * MT (192 or 256)
+// F16 (all three loops): fp16 operands on v_mfma_f32_32x32x16_f16 (SKIMI_PREC_F16); EPI 3 then writes fp16 rows (the
+// MLP's hidden activation, fc2's operand), EPI 1 still bf16 rows (qkv: the attention products stay bf16)
+template <int MT, int EPI, bool F16 = false>   // M tiles of 32 rows per wave: BM = 64 * MT (192 or 256)
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     constexpr int BM = 64 * MT, BN = 256, BK = 64;
     constexpr int RB = 128;                    // LDS row bytes
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1][i], wf[s & 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16<F16>(af[s & 1][i], wf[s & 1][j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    epilogue256<MT, EPI>(p, acc, smem, wave, lane, wr, wc, m0, n0);
+    epilogue256<MT, EPI, 2, F16 && EPI == 3>(p, acc, smem, wave, lane, wr, wc, m0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at their maxima)
 #define SKIMI_VMCNT(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))
 
-template <int EPI, int DEEP>
+template <int EPI, int DEEP, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GemmArgs p) {
     constexpr int MT = 4, BM = 256, BN = 256, BK = 64;
     constexpr int RB = 128;
@@ -444,9 +455,8 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GemmArgs p) {
         SKIMI_BAR();                                                                                             \
         __builtin_amdgcn_s_setprio(1);                                                                           \
         if (!no_mfma) _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                          \
-            acc[2 * IH][JH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s], wf[JH][s], acc[2 * IH][JH], 0, 0, 0); \
-            acc[2 * IH + 1][JH] =                                                                                \
-                __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s], wf[JH][s], acc[2 * IH + 1][JH], 0, 0, 0);      \
+            acc[2 * IH][JH] = mfma_32x32x16<F16>(af[0][s], wf[JH][s], acc[2 * IH][JH]);                           \
+            acc[2 * IH + 1][JH] = mfma_32x32x16<F16>(af[1][s], wf[JH][s], acc[2 * IH + 1][JH]);                   \
         }                                                                                                        \
         __builtin_amdgcn_s_setprio(0);                                                                           \
         SKIMI_BAR();                                                                                             \
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GemmArgs p) {
     }
     if (wr == 0) SKIMI_BAR();   // re-align the two wave rows: nobody reads operand tiles any more
 
-    epilogue256<MT, EPI>(p, acc, smem, wave, lane, wr, wc, m0, n0);
+    epilogue256<MT, EPI, 2, F16 && EPI == 3>(p, acc, smem, wave, lane, wr, wc, m0, n0);
 }
 
 
@@ -498,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GemmArgs p) {
 //   k-step 1, 2 of kt : issue (kt+2; q = 0), (kt+2; q = 1)      -> the slots K-tile kt-1's W left
 //   k-step 3 of kt    : lgkmcnt(0), vmcnt(8) = all of kt+1 landed, barrier (= K-tile kt released),
 //                       read (kt+1, k-step 0), issue (kt+2; q = 2, 3) -> K-tile kt's A slots
-template <int EPI>
+template <int EPI, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const GemmArgs p) {
     constexpr int RB = 128, BK = 64, PIECE = 128 * RB, NSLOT = 10;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const GemmArgs p) {
                 for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
 #define SKIMI_W4_MFMA(FA, FB)                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 4; ++i)                 \
-        acc[j >> 1][i][j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], FB[j], acc[j >> 1][i][j & 1], 0, 0, 0)
+        acc[j >> 1][i][j & 1] = mfma_32x32x16<F16>(FA[i], FB[j], acc[j >> 1][i][j & 1])
 
     // prologue: K-tiles 0 and 1 whole
 #pragma unroll
@@ -648,8 +658,8 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const GemmArgs p) {
     __builtin_amdgcn_s_waitcnt(0xC07F);
     SKIMI_BAR();   // nobody reads operand pieces any more: the epilogue slabs alias slots 0 and 1
 
-    epilogue256<4, EPI, 4>(p, acc[0], smem, wave, lane, wr, 2 * wc, m0, n0);
-    epilogue256<4, EPI, 4>(p, acc[1], smem, wave, lane, wr, 2 * wc + 1, m0, n0);
+    epilogue256<4, EPI, 4, F16 && EPI == 3>(p, acc[0], smem, wave, lane, wr, 2 * wc, m0, n0);
+    epilogue256<4, EPI, 4, F16 && EPI == 3>(p, acc[1], smem, wave, lane, wr, 2 * wc + 1, m0, n0);
 }
 
 
@@ -863,9 +873,10 @@ static int epi_kind(const GemmArgs& a) {
     const bool plain = a.vec4 && a.store_mode == 0 && a.out_rpb == 0 && a.out_off == 0 && a.out2 == nullptr &&
                        a.resid2 == nullptr && a.post_act == SKIMI_ACT_NONE && a.N % 4 == 0;
     if (!plain) return 0;
-    if (a.out_dtype == SKIMI_BF16 && a.gamma == nullptr && a.resid == nullptr) {
-        if (a.act == SKIMI_ACT_NONE) return 1;
-        if (a.act == SKIMI_ACT_GELU) return 3;
+    if (a.gamma == nullptr && a.resid == nullptr && (a.out_dtype == SKIMI_BF16 || a.out_dtype == SKIMI_F16)) {
+        // the 16-bit format a compile-time epilogue writes is fixed by the kernel: bf16, except EPI 3 of the fp16 loops
+        if (a.act == SKIMI_ACT_NONE && a.out_dtype == SKIMI_BF16) return 1;
+        if (a.act == SKIMI_ACT_GELU && a.out_dtype == (a.f16 ? SKIMI_F16 : SKIMI_BF16)) return 3;
         return 0;
     }
     if (a.out_dtype == SKIMI_FP8MX && a.out_scales != nullptr && a.gamma == nullptr && a.resid == nullptr && a.bias != nullptr &&
@@ -878,78 +889,83 @@ static int epi_kind(const GemmArgs& a) {
 }
 
 bool gemm256_eligible(const skimi_gemm_desc* d) {
-    return d->prec == SKIMI_PREC_BF16 && d->a_dtype == SKIMI_BF16 && d->w_dtype == SKIMI_BF16 && d->a_mode == 0 &&
+    const bool bf = d->prec == SKIMI_PREC_BF16 && d->a_dtype == SKIMI_BF16 && d->w_dtype == SKIMI_BF16;
+    const bool hf = d->prec == SKIMI_PREC_F16 && d->a_dtype == SKIMI_F16 && d->w_dtype == SKIMI_F16;
+    return (bf || hf) && d->a_mode == 0 &&
            d->store_mode == 0 && d->K % 64 == 0 && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->M >= 2048 &&
            d->N >= 512 && (((uintptr_t)d->A | (uintptr_t)d->W) & 15) == 0;
 }
 
-template <int MT, int EPI>
+template <int MT, int EPI, bool F16 = false>
 static int launch256(GemmArgs& a, hipStream_t st) {
     constexpr size_t lds = 2ull * (64 * MT + 256) * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<MT, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(gemm256) failed: %s", hipGetErrorString(e));
-            return SKIMI_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    SKIMI_LDS_OPT_IN((gemm256_kernel<MT, EPI, F16>), lds, "gemm256");
     a.ntm = (int)cdiv(a.M, 64 * MT);
     a.ntn = (int)cdiv(a.N, 256);
     a.splitk = 1;
-    hipLaunchKernelGGL((gemm256_kernel<MT, EPI>), dim3(a.ntm * a.ntn), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((gemm256_kernel<MT, EPI, F16>), dim3(a.ntm * a.ntn), dim3(512), lds, st, a);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }
 
-template <int EPI, int DEEP>
+template <int EPI, int DEEP, bool F16 = false>
 static int launch256pp_(GemmArgs& a, hipStream_t st) {
     constexpr size_t lds = 2ull * (256 + 256) * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256pp_kernel<EPI, DEEP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(gemm256pp) failed: %s", hipGetErrorString(e));
-            return SKIMI_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    SKIMI_LDS_OPT_IN((gemm256pp_kernel<EPI, DEEP, F16>), lds, "gemm256pp");
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
     a.splitk = 1;
-    hipLaunchKernelGGL((gemm256pp_kernel<EPI, DEEP>), dim3(a.ntm * a.ntn), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((gemm256pp_kernel<EPI, DEEP, F16>), dim3(a.ntm * a.ntn), dim3(512), lds, st, a);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }
 
-template <int EPI>
+template <int EPI, bool F16 = false>
 static int launch256pp(GemmArgs& a, hipStream_t st) {
+    if constexpr (F16) return launch256pp_<EPI, 1, true>(a, st);
     const int deep = SKIMI_ENV_INT("SKIMI_GEMM256_DEEP", 1);
     return deep ? launch256pp_<EPI, 1>(a, st) : launch256pp_<EPI, 0>(a, st);
 }
 
-template <int EPI>
+template <int EPI, bool F16 = false>
 static int launch256w4(GemmArgs& a, hipStream_t st) {
     constexpr size_t lds = 10ull * 128 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256w4_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(gemm256w4) failed: %s", hipGetErrorString(e));
-            return SKIMI_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    SKIMI_LDS_OPT_IN((gemm256w4_kernel<EPI, F16>), lds, "gemm256w4");
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
     a.splitk = 1;
-    hipLaunchKernelGGL((gemm256w4_kernel<EPI>), dim3(a.ntm * a.ntn), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((gemm256w4_kernel<EPI, F16>), dim3(a.ntm * a.ntn), dim3(256), lds, st, a);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
+}
+
+template <bool F16>
+static int gemm256_pick(GemmArgs& a, hipStream_t st, int epi, bool mt3, bool w4, int use_pp) {
+    if (mt3) {
+        if (epi == 1) return launch256<3, 1, F16>(a, st);
+        if (epi == 2) return launch256<3, 2, F16>(a, st);
+        if (epi == 3) return launch256<3, 3, F16>(a, st);
+        return launch256<3, 0, F16>(a, st);
+    }
+    if (w4) {
+        if (epi == 1) return launch256w4<1, F16>(a, st);
+        if (epi == 2) return launch256w4<2, F16>(a, st);
+        if (epi == 3) return launch256w4<3, F16>(a, st);
+        return launch256w4<0, F16>(a, st);
+    }
+    if (use_pp || F16) {   // the fp16 build carries the two loops the dispatch picks (single-stream, ping-pong) + the 192-row one
+        if (epi == 1) return launch256pp<1, F16>(a, st);
+        if (epi == 2) return launch256pp<2, F16>(a, st);
+        if (epi == 3) return launch256pp<3, F16>(a, st);
+        return launch256pp<0, F16>(a, st);
+    }
+    if constexpr (!F16) {
+        if (epi == 1) return launch256<4, 1>(a, st);
+        if (epi == 2) return launch256<4, 2>(a, st);
+        if (epi == 3) return launch256<4, 3>(a, st);
+        return launch256<4, 0>(a, st);
+    }
+    return SKIMI_ERR_ARG;
 }
 
 // pick the tile height (192 or 256 rows) that wastes the fewest CU-rounds for this shape:
@@ -975,44 +991,15 @@ int gemm256_launch(GemmArgs& a, hipStream_t st) {
     const int use_pp = SKIMI_ENV_INT("SKIMI_GEMM256_PP", 1);
     const int use_mt3 = SKIMI_ENV_INT("SKIMI_GEMM256_MT3", -1);
     const int use_w4 = SKIMI_ENV_INT("SKIMI_GEMM256_W4", -1);
-    if (use_mt3 == 1 || (use_mt3 < 0 && cost(192) < 0.8 * cost(256))) {
-        if (epi == 1) return launch256<3, 1>(a, st);
-        if (epi == 2) return launch256<3, 2>(a, st);
-        if (epi == 3) return launch256<3, 3>(a, st);
-        return launch256<3, 0>(a, st);
-    }
+    const bool mt3 = use_mt3 == 1 || (use_mt3 < 0 && cost(192) < 0.8 * cost(256));
     const bool w4 = use_w4 >= 0 ? use_w4 != 0 : (epi == 1 || (epi == 2 && a.K > 1024));
-    if (w4) {
-        if (epi == 1) return launch256w4<1>(a, st);
-        if (epi == 2) return launch256w4<2>(a, st);
-        if (epi == 3) return launch256w4<3>(a, st);
-        return launch256w4<0>(a, st);
-    }
-    if (use_pp) {
-        if (epi == 1) return launch256pp<1>(a, st);
-        if (epi == 2) return launch256pp<2>(a, st);
-        if (epi == 3) return launch256pp<3>(a, st);
-        return launch256pp<0>(a, st);
-    }
-    if (epi == 1) return launch256<4, 1>(a, st);
-    if (epi == 2) return launch256<4, 2>(a, st);
-    if (epi == 3) return launch256<4, 3>(a, st);
-    return launch256<4, 0>(a, st);
+    return a.f16 ? gemm256_pick<true>(a, st, epi, mt3, w4, use_pp) : gemm256_pick<false>(a, st, epi, mt3, w4, use_pp);
 }
 
 template <int EPI>
 static int launch256w4_fp8(GemmArgs& a, hipStream_t st) {
     constexpr size_t lds = 10ull * 128 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256w4_fp8_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(gemm256w4_fp8) failed: %s", hipGetErrorString(e));
-            return SKIMI_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    SKIMI_LDS_OPT_IN(gemm256w4_fp8_kernel<EPI>, lds, "gemm256w4_fp8");
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
     a.splitk = 1;

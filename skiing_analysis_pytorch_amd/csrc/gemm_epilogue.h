@@ -38,6 +38,7 @@ struct GemmArgs {
     float* partial;    // [M, N] fp32, zeroed
     int ntm, ntn;
     int vec4;          // epilogue may use 16-B accesses (N, ld*, pointers all 4-element aligned)
+    int f16;           // 16-bit operands are fp16 and the MFMA is the f16 one (SKIMI_PREC_F16)
     int dbg;           // diagnostics only (gemm256 ablation: bit0 skip staging, bit1 skip MFMA phase)
     unsigned short* out_rec;   // or NULL: result rows also as bf16x3 records [M][N/32][hi 32 | lo 32]
     long rec_row;              // elements per record row = N/32 * 64
@@ -197,7 +198,7 @@ __device__ __forceinline__ void store_one(const GemmArgs& p, const RowMap& rm, i
         ((float*)p.out)[o] = v;
         if (p.out2) ((unsigned short*)p.out2)[o2] = f2bf(v);
     } else {
-        ((unsigned short*)p.out)[o] = f2bf(v);
+        ((unsigned short*)p.out)[o] = f2x16(v, p.out_dtype == SKIMI_F16);
         if (p.out2) ((float*)p.out2)[o2] = v;
     }
 }
@@ -243,9 +244,10 @@ __device__ __forceinline__ void store_four(const GemmArgs& p, const RowMap& rm, 
     }
     if (p.out_rec) store_rec4(p, rm.row, n, v[0], v[1], v[2], v[3]);
     if (!p.out) return;
-    bf16x4 hb;
+    bf16x4 hb;   // the 16-bit copy: bf16, or fp16 when that is the output type (out2 of an fp32 result is always bf16)
+    const bool h16 = p.out_dtype == SKIMI_F16;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hb[k] = (short)f2bf(v[k]);
+    for (int k = 0; k < 4; ++k) hb[k] = (short)f2x16(v[k], h16);
     const float4 fv = make_float4(v[0], v[1], v[2], v[3]);
     if (p.out_dtype == SKIMI_F32) {
         *reinterpret_cast<float4*>((float*)p.out + o) = fv;

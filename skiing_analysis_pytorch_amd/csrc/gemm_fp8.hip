@@ -304,6 +304,7 @@ int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws
     SKIMI_CHECK_ARG(out_dtype == SKIMI_F32 || out_dtype == SKIMI_BF16 || out_dtype == SKIMI_FP8MX, "gemm_fp8: output must be fp32, bf16 or MXFP8");
     SKIMI_CHECK_ARG(out_dtype != SKIMI_FP8MX || (out_scales && act == SKIMI_ACT_GELU && !gamma && !resid && bias && N % 128 == 0 && ldo == N),
                     "gemm_fp8: MXFP8 output needs out_scales, the bias + GELU epilogue, N %% 128 == 0 and ldo == N");
+    SKIMI_CHECK_ARG((((uintptr_t)As | (uintptr_t)Ws) & 3) == 0, "gemm_fp8: the scale arrays are read as dwords (4-byte aligned; K padded to 128 keeps every row so)");
     SKIMI_CHECK_ARG(act == SKIMI_ACT_NONE || act == SKIMI_ACT_GELU, "gemm_fp8: activation must be none or GELU");
     SKIMI_CHECK_ARG(!(gamma != nullptr) || resid != nullptr, "gemm_fp8: LayerScale needs the residual");
     SKIMI_CHECK_ARG(!(act == SKIMI_ACT_GELU && gamma), "gemm_fp8: GELU and LayerScale epilogues are separate");
@@ -351,12 +352,7 @@ int gemm_fp8_launch(const void* A, const void* As, const void* W, const void* Ws
 #define SKIMI_FP8_LAUNCH(E, T)                                                                                          \
     do {                                                                                                                \
         constexpr int lds = 4 * 64 * T * 128;                                                                           \
-        static bool attr = false;                                                                                       \
-        if (lds > 64 * 1024 && !attr) {                                                                                 \
-            SKIMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_kernel<E, T>),                         \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));                            \
-            attr = true;                                                                                                \
-        }                                                                                                               \
+        if (lds > 64 * 1024) SKIMI_LDS_OPT_IN((gemm_fp8_kernel<E, T>), lds, "gemm_fp8");                                \
         hipLaunchKernelGGL((gemm_fp8_kernel<E, T>), dim3((unsigned)nblk), dim3(256), lds, st, p);                       \
     } while (0)
     if (big) {

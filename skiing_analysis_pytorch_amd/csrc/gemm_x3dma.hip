@@ -780,16 +780,7 @@ bool gemm_x3dma_eligible(const skimi_gemm_desc* d) {
 template <int AMODE, int ABL = 0>
 static int launch_x3w4(GemmArgs& a, const X3Rec& pl, hipStream_t st) {
     constexpr size_t lds = 10ull * 128 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w4_kernel<AMODE, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(gemm_x3w4) failed: %s", hipGetErrorString(e));
-            return SKIMI_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    SKIMI_LDS_OPT_IN((gemm_x3w4_kernel<AMODE, ABL>), lds, "gemm_x3w4");
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 256);
     a.splitk = 1;
@@ -801,16 +792,7 @@ static int launch_x3w4(GemmArgs& a, const X3Rec& pl, hipStream_t st) {
 template <int AMODE>
 static int launch_x3w4n(GemmArgs& a, const X3Rec& pl, hipStream_t st) {
     constexpr size_t lds = 9ull * 128 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3w4n_kernel<AMODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(gemm_x3w4n) failed: %s", hipGetErrorString(e));
-            return SKIMI_ERR_HIP;
-        }
-        attr_done = true;
-    }
+    SKIMI_LDS_OPT_IN(gemm_x3w4n_kernel<AMODE>, lds, "gemm_x3w4n");
     a.ntm = (int)cdiv(a.M, 256);
     a.ntn = (int)cdiv(a.N, 128);
     a.splitk = 1;

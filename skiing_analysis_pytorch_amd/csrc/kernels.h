@@ -35,6 +35,7 @@ struct AttnArgs {
     int batch_inner = 0;
     long q_batch2 = 0, k_batch2 = 0, v_batch2 = 0, o_batch2 = 0;
     int q_prescaled = 0;   // bf16 kernels: q already carries scale * log2(e) (qknorm_rope_launch's q_scale)
+    int out_f16 = 0;       // bf16 kernels: the output rows are written as fp16 (proj's operand under SKIMI_PREC_F16)
 };
 int attention_f32_launch(const AttnArgs& a, hipStream_t st);
 int attention_bf16_launch(const AttnArgs& a, hipStream_t st);
@@ -51,7 +52,8 @@ int conv_direct_n32_launch(const unsigned short* in_hi, const unsigned short* in
 void attention_q64_dispatch(const AttnArgs& a, hipStream_t st);    // attention_q64.hip: 64 queries per wave
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
                      hipStream_t st, int q_prescaled = 0, void* x3_scratch = nullptr, size_t x3_scratch_bytes = 0,
-                     int* out_records = nullptr);   // in: bf16x3 records wanted in `out` (fp32 mode); out: whether they were written
+                     int* out_records = nullptr,    // in: bf16x3 records wanted in `out` (fp32 mode); out: whether they were written
+                     int out_f16 = 0);              // bf16 q / k / v, fp16 output rows (SKIMI_PREC_F16)
 // attention_x3.hip: fp32-accurate attention (head_dim 64) on the bf16 matrix pipe, operands split hi + lo; needs
 // scratch for the hi / lo planes of the packed qkv buffer (attention_launch uses it for fp32 inputs when given)
 size_t attention_x3_scratch_bytes(long tokens, long row_elems);

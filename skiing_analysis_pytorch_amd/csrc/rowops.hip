@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (gamma) y *= gamma[c];
             if (beta) y += beta[c];
             if (out_dtype == SKIMI_F32) ((float*)out)[orow * ldo + c] = y;
-            else ((unsigned short*)out)[orow * ldo + c] = f2bf(y);
+            else ((unsigned short*)out)[orow * ldo + c] = f2x16(y, out_dtype == SKIMI_F16);
         }
     }
 }
@@ -123,9 +123,10 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
             unsigned short* q = (unsigned short*)out + orow * (2L * C) + (c >> 5) * 64 + (c & 31);
             *reinterpret_cast<bf16x4*>(q) = h;
             *reinterpret_cast<bf16x4*>(q + 32) = l;
-        } else {
+        } else {   // bf16, or fp16 (the operand of SKIMI_PREC_F16's Linears)
+            const bool h16 = out_dtype == SKIMI_F16;
             bf16x4 h;
-            h[0] = (short)f2bf(y[0]); h[1] = (short)f2bf(y[1]); h[2] = (short)f2bf(y[2]); h[3] = (short)f2bf(y[3]);
+            h[0] = (short)f2x16(y[0], h16); h[1] = (short)f2x16(y[1], h16); h[2] = (short)f2x16(y[2], h16); h[3] = (short)f2x16(y[3], h16);
             *reinterpret_cast<bf16x4*>((unsigned short*)out + orow * ldo + c) = h;
         }
     }
@@ -140,6 +141,8 @@ int layernorm_launch(const float* x, const float* x2, int64_t ldx, int64_t rows,
     SKIMI_CHECK_ARG(x && out && rows > 0 && C > 0, "skimi_layernorm: bad arguments");
     SKIMI_CHECK_ARG(C <= 64 * 32, "skimi_layernorm: C=%d exceeds 2048", C);
     SKIMI_CHECK_ARG(x2 == nullptr || (C % 2 == 0), "skimi_layernorm: concat needs even C");
+    SKIMI_CHECK_ARG(out_dtype == SKIMI_F32 || out_dtype == SKIMI_BF16 || out_dtype == SKIMI_F16 || out_dtype == SKIMI_BF16X3_REC,
+                    "skimi_layernorm: bad out_dtype %d", out_dtype);
     dim3 grid((unsigned)cdiv(rows, 4)), block(256);
     SKIMI_CHECK_ARG(out_dtype != SKIMI_BF16X3_REC || (C % 256 == 0 && ((uintptr_t)out & 127) == 0),
                     "skimi_layernorm: records output needs C %% 256 == 0 and a 128-byte aligned buffer");

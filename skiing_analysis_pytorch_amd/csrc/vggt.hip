@@ -195,11 +195,11 @@ struct Packer {
             m = (float*)dmalloc((size_t)N * L.K * 4);
             if (m && (rc = pad_cols_launch(src, m, N, K, L.K, st))) return L;
         }
-        if (prec == SKIMI_PREC_BF16) {
+        if (prec == SKIMI_PREC_BF16 || prec == SKIMI_PREC_F16) {
             void* b = dmalloc((size_t)N * L.K * 2);
-            if (b) rc = f32_to_bf16_launch(m, b, (long)N * L.K, st);
+            if (b) rc = prec == SKIMI_PREC_F16 ? f32_to_f16_launch(m, b, (long)N * L.K, st) : f32_to_bf16_launch(m, b, (long)N * L.K, st);
             L.w = b;
-            L.wdt = SKIMI_BF16;
+            L.wdt = prec == SKIMI_PREC_F16 ? SKIMI_F16 : SKIMI_BF16;
         } else {
             if (m == src) {   // private copy: the staged buffer is released after finalize
                 m = (float*)dmalloc((size_t)N * L.K * 4);
@@ -374,7 +374,8 @@ struct Ctx {
     size_t slab_bytes = 0;
 
     bool dry() const { return ar.dry; }
-    static int act_dt(int prec) { return prec == SKIMI_PREC_BF16X3 ? SKIMI_F32 : SKIMI_BF16; }   // BF16 and FP8 modes: bf16 activations
+    // operand format of the Linears' activations: fp32 (split hi + lo by the kernels), fp16, or bf16 (BF16 and FP8 modes)
+    static int act_dt(int prec) { return prec == SKIMI_PREC_BF16X3 ? SKIMI_F32 : prec == SKIMI_PREC_F16 ? SKIMI_F16 : SKIMI_BF16; }
     static size_t esz(int dt) { return dt == SKIMI_F32 ? 4 : 2; }
 
     void gemm(skimi_gemm_desc& d) {
@@ -431,6 +432,10 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
     const int M = batch * seq;
     const int prec = w.qkv.prec;
     const int adt = Ctx::act_dt(prec);
+    // the packed q / k / v buffer: SKIMI_PREC_F16 keeps the attention products on bf16 operands (they average their rounding
+    // noise over all keys: profiles/r03_precision_ablation.md), so qkv's epilogue writes bf16 and the attention kernel
+    // converts its output to fp16 for proj
+    const int qdt = adt == SKIMI_F16 ? SKIMI_BF16 : adt;
     const int hidden = w.fc1.N;
     const bool fp8 = w.qkv.wq != nullptr && b.q8 != nullptr;   // SKIMI_PREC_FP8: qkv, fc1, fc2 on the MXFP8 MFMA
     // the quantisation rides in the producers where the shapes allow: LayerNorm writes MXFP8 directly (C % 256 == 0), and
@@ -445,7 +450,7 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
         return d;
     };
     const bool x3 = adt == SKIMI_F32 && C % 256 == 0;
-    auto d_qkv = c.desc(w.qkv, b.xn, adt, C, M, b.qkv, adt, 3 * C);
+    auto d_qkv = c.desc(w.qkv, b.xn, adt, C, M, b.qkv, qdt, 3 * C);
     bool rec_qkv = false;
     if (x3) {
         const auto q = as_records(d_qkv, b.xn, (size_t)M * C * 4);
@@ -469,9 +474,9 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
         // bf16 mode: the softmax scale (x log2 e) rides in q's one rounding to bf16, the attention kernel then
         // exponentiates the raw accumulator
         const float q_scale = (1.0f / sqrtf((float)(C / heads))) * 1.44269504088896340736f;
-        c.rc = qknorm_rope_launch(b.qkv, adt, M, heads, w.qn_w, w.qn_b, w.kn_w, w.kn_b, 1e-5f, rope ? c.tabs->pos : nullptr,
+        c.rc = qknorm_rope_launch(b.qkv, qdt, M, heads, w.qn_w, w.qn_b, w.kn_w, w.kn_b, 1e-5f, rope ? c.tabs->pos : nullptr,
                                   c.tabs->rope_cos, c.tabs->rope_sin, c.tabs->rope_npos, c.st, q_scale,
-                                  adt == SKIMI_BF16 && C / heads == 64 ? &q_scaled : nullptr);
+                                  qdt == SKIMI_BF16 && C / heads == 64 ? &q_scaled : nullptr);
     }
     // fp32-accurate mode: the MLP's hidden buffer (M x hidden fp32, idle until fc1) lends the hi / lo planes of k and v; the
     // attention kernel writes proj's operand records when proj runs on the LDS-DMA kernel
@@ -483,8 +488,8 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
         ao_rec = gemm_x3dma_eligible(&q) ? 1 : 0;
     }
     if (!c.rc && !c.dry())
-        c.rc = attention_launch(b.qkv, b.ao, adt, batch, seq, heads, C / heads, c.st, q_scaled, adt == SKIMI_F32 ? b.hid : nullptr,
-                                adt == SKIMI_F32 ? (size_t)M * hidden * 4 : 0, &ao_rec);
+        c.rc = attention_launch(b.qkv, b.ao, qdt, batch, seq, heads, C / heads, c.st, q_scaled, adt == SKIMI_F32 ? b.hid : nullptr,
+                                adt == SKIMI_F32 ? (size_t)M * hidden * 4 : 0, &ao_rec, adt == SKIMI_F16);
     if (ao_rec && !c.dry()) d_proj = as_records(d_proj, b.ao, (size_t)M * C * 4);
     c.gemm(d_proj);
     auto d_fc1 = c.desc(w.fc1, b.xn, adt, C, M, b.hid, adt, hidden);
@@ -1058,6 +1063,14 @@ skimi_vggt* skimi_vggt_create(const skimi_vggt_config* cfg) {
             set_error("skimi_vggt_create: dpt_layers[%d] = %d outside [0, depth)", i, cfg->dpt_layers[i]);
             return nullptr;
         }
+    if (cfg->prec < SKIMI_PREC_BF16 || cfg->prec > SKIMI_PREC_F16) {
+        set_error("skimi_vggt_create: prec %d is not one of SKIMI_PREC_BF16 / BF16X3 / FP8 / F16", cfg->prec);
+        return nullptr;
+    }
+    if (cfg->head_prec != SKIMI_PREC_BF16 && cfg->head_prec != SKIMI_PREC_BF16X3) {
+        set_error("skimi_vggt_create: head_prec %d: the heads run in SKIMI_PREC_BF16X3 (the reference's fp32) or SKIMI_PREC_BF16", cfg->head_prec);
+        return nullptr;
+    }
     skimi_vggt* h = new skimi_vggt();
     h->cfg = *cfg;
     return h;

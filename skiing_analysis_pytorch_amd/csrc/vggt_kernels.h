@@ -19,6 +19,7 @@ int pose_update_launch(const float* delta, float* pred_pad, float* act_out, long
 int dpt_out_launch(const void* in, int dtype, const float* W, const float* b, int n_out, float* pts, float* conf,
                    long npix, int mode, hipStream_t st);
 int f32_to_bf16_launch(const float* in, void* out, long n, hipStream_t st);
+int f32_to_f16_launch(const float* in, void* out, long n, hipStream_t st);
 int permute_conv_launch(const float* in, float* out, int Co, int Ci, int kh, int kw, hipStream_t st, int slice_major = 0);
 int permute_convT_launch(const float* in, float* out, int Ci, int Co, int s, hipStream_t st);
 int pad_cols_launch(const float* in, float* out, long rows, int K, int Kp, hipStream_t st);

@@ -19,7 +19,7 @@ static inline int grid_for(long n, int per_block = 256, int cap = 8192) {
 // (vggt/vggt/models/aggregator.py:201 + the im2col of patch_embed.py:62,72-74's Conv2d k=s=14;
 //  column order = Conv2d weight.flatten(1) order, zero padded to Kp)
 // ---------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool F16 = false>
 __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ img, T* __restrict__ out,
                                                            int F, int H, int W, int p, int Kp) {
     const int ph = H / p, pw = W / p, K = 3 * p * p;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restri
             v = (x - mean[c]) / stdv[c];
         }
         if (sizeof(T) == 4) ((float*)out)[i] = v;
-        else ((unsigned short*)out)[i] = f2bf(v);
+        else ((unsigned short*)out)[i] = F16 ? f2h(v) : f2bf(v);
     }
 }
 
@@ -50,6 +50,9 @@ int patch_gather_launch(const float* img, void* out, int out_dtype, int F, int H
     const long total = (long)F * (H / p) * (W / p) * Kp;
     if (out_dtype == SKIMI_F32)
         hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, img, (float*)out, F, H, W, p, Kp);
+    else if (out_dtype == SKIMI_F16)
+        hipLaunchKernelGGL((patch_gather_kernel<unsigned short, true>), dim3(grid_for(total)), dim3(256), 0, st, img,
+                           (unsigned short*)out, F, H, W, p, Kp);
     else
         hipLaunchKernelGGL(patch_gather_kernel<unsigned short>, dim3(grid_for(total)), dim3(256), 0, st, img,
                            (unsigned short*)out, F, H, W, p, Kp);
@@ -398,6 +401,14 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ in, unsigned short*
 }
 int f32_to_bf16_launch(const float* in, void* out, long n, hipStream_t st) {
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, (unsigned short*)out, n);
+    SKIMI_LAUNCH_CHECK();
+    return SKIMI_OK;
+}
+__global__ void f32_to_f16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = f2h(in[i]);
+}
+int f32_to_f16_launch(const float* in, void* out, long n, hipStream_t st) {
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, (unsigned short*)out, n);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }

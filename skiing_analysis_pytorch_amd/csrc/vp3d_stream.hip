@@ -483,12 +483,8 @@ __global__ __launch_bounds__(512) void vp3d_conv_kernel(const Vp3dConv p) {
 template <int CT, int RT, int TAPS, int XF32 = 0>
 static int launch_conv(const Vp3dConv& p, int grid, hipStream_t st) {
     constexpr int lds = 8 * TAPS * (CT / 16) * RT * 1024;
-    static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in, once per kernel
-    if (lds > 64 * 1024 && !attr_done) {
-        SKIMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vp3d_conv_kernel<CT, RT, TAPS, XF32>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
-    }
+    if (lds > 64 * 1024)   // > 64 KiB of dynamic LDS needs the opt-in, once per kernel and device
+        SKIMI_LDS_OPT_IN((vp3d_conv_kernel<CT, RT, TAPS, XF32>), lds, "vp3d_conv");
     hipLaunchKernelGGL((vp3d_conv_kernel<CT, RT, TAPS, XF32>), dim3(grid), dim3(512), lds, st, p);
     return SKIMI_OK;
 }

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, BF16, F32, PREC_BF16, PREC_BF16X3, GemmDesc, check, lib, ptr
+from ._lib import ACT_NONE, BF16, F16, F32, PREC_BF16, PREC_BF16X3, GemmDesc, check, lib, ptr
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -16,6 +16,8 @@ def _dt(t: torch.Tensor) -> int:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
@@ -125,12 +127,17 @@ def qknorm_rope_(qkv, heads, qn_w=None, qn_b=None, kn_w=None, kn_b=None, eps=1e-
     return qkv
 
 
-def attention(qkv, batch, seq, heads, head_dim):
-    """qkv: [batch*seq, 3*heads*head_dim] -> [batch*seq, heads*head_dim] (same dtype)"""
+def attention(qkv, batch, seq, heads, head_dim, out_dtype=None):
+    """qkv: [batch*seq, 3*heads*head_dim] -> [batch*seq, heads*head_dim] (same dtype; out_dtype=torch.float16 with
+    bf16 qkv: the result rows as fp16, PREC_F16's proj operand)"""
     _require_cuda(qkv)
-    out = torch.empty((batch * seq, heads * head_dim), dtype=qkv.dtype, device=qkv.device)
-    check(lib().skimi_attention(ptr(qkv), ptr(out), _dt(qkv), batch, seq, heads, head_dim, _lib.current_stream()),
-          "skimi_attention")
+    out = torch.empty((batch * seq, heads * head_dim), dtype=out_dtype or qkv.dtype, device=qkv.device)
+    if out_dtype is None or out_dtype == qkv.dtype:
+        check(lib().skimi_attention(ptr(qkv), ptr(out), _dt(qkv), batch, seq, heads, head_dim, _lib.current_stream()),
+              "skimi_attention")
+    else:
+        check(lib().skimi_attention_out(ptr(qkv), ptr(out), _dt(qkv), _dt(out), batch, seq, heads, head_dim,
+                                        _lib.current_stream()), "skimi_attention_out")
     return out
 
 
@@ -211,6 +218,13 @@ def gemm_fp8(a_q, a_s, w_q, w_s, K, *, bias=None, act=ACT_NONE, gamma=None, resi
     out_mx: return (payload uint8 [M, N], scales uint8 [M, N / 32]) -- the result directly as the next gemm_fp8's operand."""
     _require_cuda(a_q, a_s, w_q, w_s, bias, gamma, resid, out)
     M, N = a_q.shape[0], w_q.shape[0]
+    Kp = (K + 127) // 128 * 128
+    for t, cols, what in ((a_q, Kp, "a_q"), (w_q, Kp, "w_q"), (a_s, Kp // 32, "a_s"), (w_s, Kp // 32, "w_s")):
+        if t.dtype != torch.uint8 or t.dim() != 2 or t.shape[1] != cols or not t.is_contiguous():
+            raise _lib.SkimiError(f"gemm_fp8: {what} must be a contiguous uint8 [rows, {cols}] array for K = {K} "
+                                  f"(got {tuple(t.shape)} {t.dtype}); operands come from quant_mx")
+    if a_s.shape[0] != M or w_s.shape[0] != N:
+        raise _lib.SkimiError("gemm_fp8: scale rows do not match the payload rows")
     if out_mx:
         q = torch.empty((M, N), dtype=torch.uint8, device=a_q.device)
         sc = torch.empty((M, N // 32), dtype=torch.uint8, device=a_q.device)
