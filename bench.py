@@ -243,7 +243,7 @@ def main():
         if pk:   # what a register-only MFMA loop delivers on this part (tools/peaks.hip): context for `frac`, which stays on the datasheet peak
             line["roofline"]["peak_measured"] = {"unit": "TFLOP/s", "random_operands": pk["random_operands"], "zero_operands": pk["zero_operands"],
                                                  "frac_of_random_operand_peak": ach / pk["random_operands"],
-                                                 "source": "static: profiles/r02_peaks.json (tools/peaks.hip, register-only v_mfma_f32_32x32x16_bf16 loop)"}
+                                                 "source": "static: profiles/r03_peaks.json (tools/peaks.hip, register-only v_mfma_f32_32x32x16_bf16 loop)"}
     if rank == 0 and world == 1 and NS > 1 and "roofline" in line:
         # outside the timed region: the same kernel with the chip to itself (one batch, one stream)
         _lib.check(lib.skimi_profile_start(1, seq_global), "profile_start")
@@ -490,7 +490,7 @@ def vp3d_traffic():
 
 
 def measured_peaks():
-    f = Path(__file__).resolve().parent / "profiles" / "r02_peaks.json"
+    f = Path(__file__).resolve().parent / "profiles" / "r03_peaks.json"
     try:
         return json.loads(f.read_text())["mfma_bf16_32x32x16_register_loop_TFLOPs"]
     except (OSError, ValueError, KeyError):

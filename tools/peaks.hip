@@ -29,6 +29,59 @@ __global__ __launch_bounds__(256) void mfma_loop(const bf16x8* in, float* out, i
     if (s == 123.456f) out[0] = s;   // keep the loop
 }
 
+// the same loop on the other shape / format: SHAPE 0 = 32x32x16, 1 = 16x16x32 (16 accumulators of 4 registers: the same
+// 64 accumulator registers and the same FLOPs per iteration); F16: fp16 operands instead of bf16
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <int SHAPE, bool F16>
+__global__ __launch_bounds__(256) void mfma_loop2(const bf16x8* in, float* out, int iters);
+
+template <bool F16>
+__device__ __forceinline__ void loop32(const bf16x8 a, const bf16x8 b, float* out, int iters) {
+    const f16x8 ah = __builtin_bit_cast(f16x8, a), bh = __builtin_bit_cast(f16x8, b);
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // inline asm with the accumulators pinned in VGPRs: hipcc's allocator otherwise shuttles half of the 16x16
+            // accumulators through v_accvgpr_mov every iteration
+            if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(ah), "v"(bh));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][7];
+    if (s == 123.456f) out[0] = s;
+}
+template <bool F16>
+__device__ __forceinline__ void loop16(const bf16x8 a, const bf16x8 b, float* out, int iters) {
+    const f16x8 ah = __builtin_bit_cast(f16x8, a), bh = __builtin_bit_cast(f16x8, b);
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(ah), "v"(bh));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a), "v"(b));
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 123.456f) out[0] = s;
+}
+template <int SHAPE, bool F16>
+__global__ __launch_bounds__(256) void mfma_loop2(const bf16x8* in, float* out, int iters) {
+    const bf16x8 a = in[threadIdx.x], b = in[256 + threadIdx.x];
+    if constexpr (SHAPE == 0) loop32<F16>(a, b, out, iters);
+    else loop16<F16>(a, b, out, iters);
+}
+
 __global__ __launch_bounds__(256) void stream_read(const f32x4* x, long n, float* out) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += __builtin_nontemporal_load(x + i);
@@ -67,6 +120,29 @@ int main() {
         hipMemcpy(din, h.data(), 512 * 16, hipMemcpyHostToDevice);
         const double ms = time_ms([&] { mfma_loop<<<blocks, 256>>>(din, dout, iters); }, 3);
         tf[pass] = (double)blocks * 4 * iters * 4 * 32768.0 / (ms * 1e-3) / 1e12;
+    }
+    // round 3: MFMA shape x operand format on random operands (MI355X_MICROARCH.md "DVFS give-back" (7): the clock the chip
+    // holds under load depends on the MFMA shape), 1 and 8 waves per SIMD, the four variants interleaved twice
+    {
+        srand(1);
+        // values with random mantissas that are ordinary numbers in BOTH formats: bf16 0x3C00.. = 0.0078.., fp16 0x3C00.. = 1.0..
+        for (auto& v : h) v = (unsigned short)(0x3C00 + (rand() & 0x3FF) + ((rand() & 1) << 15));
+        hipMemcpy(din, h.data(), 512 * 16, hipMemcpyHostToDevice);
+        printf("{\n \"mfma_shape_format_random_operands_TFLOPs\": {\n");
+        for (int wps = 1; wps <= 8; wps *= 8) {
+            const int nb = 256 * wps;
+            double t[4] = {0, 0, 0, 0};
+            for (int rep = 0; rep < 2; ++rep) {
+                t[0] += time_ms([&] { mfma_loop2<0, false><<<nb, 256>>>(din, dout, iters); }, 3);
+                t[1] += time_ms([&] { mfma_loop2<1, false><<<nb, 256>>>(din, dout, iters); }, 3);
+                t[2] += time_ms([&] { mfma_loop2<0, true><<<nb, 256>>>(din, dout, iters); }, 3);
+                t[3] += time_ms([&] { mfma_loop2<1, true><<<nb, 256>>>(din, dout, iters); }, 3);
+            }
+            const double fl = (double)nb * 4 * iters * 4 * 32768.0;
+            printf("  \"%d_waves_per_simd\": {\"bf16_32x32x16\": %.0f, \"bf16_16x16x32\": %.0f, \"f16_32x32x16\": %.0f, \"f16_16x16x32\": %.0f}%s\n", wps,
+                   fl / (t[0] / 2 * 1e-3) / 1e12, fl / (t[1] / 2 * 1e-3) / 1e12, fl / (t[2] / 2 * 1e-3) / 1e12, fl / (t[3] / 2 * 1e-3) / 1e12, wps == 1 ? "," : "");
+        }
+        printf(" }\n}\n");
     }
     const long n = (4l << 30) / 16;
     f32x4 *x, *y;
