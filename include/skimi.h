@@ -329,6 +329,11 @@ int skimi_vggt_finalize(skimi_vggt*);
  * the host side (skiing_analysis_pytorch_amd/vggt.py); without it such sizes are rejected. */
 int skimi_vggt_set_pos_embed(skimi_vggt*, int32_t H, int32_t W, const float* pos_embed, int32_t on_device);
 size_t skimi_vggt_workspace_bytes(skimi_vggt*, int32_t B, int32_t S, int32_t H, int32_t W, int32_t n_query);
+/* The RoPE position table the forward uses for `frames` frames of H x W: dev int32 [frames, P, 2] (y, x), P = 1 +
+ * num_register_tokens + (H/patch)*(W/patch); patches carry (row + 1, column + 1), the special tokens (0, 0)
+ * (PositionGetter, vggt/vggt/layers/rope.py:39-59, + the offset of aggregator.py:219-228).  An index path: the
+ * parity tests compare it bit for bit.  Synchronous copy; builds the handle's table for this shape if needed. */
+int skimi_vggt_rope_positions(skimi_vggt*, int32_t frames, int32_t H, int32_t W, int32_t* positions);
 
 /* device output buffers (fp32); a NULL pointer skips the store (a head whose outputs are all
  * NULL is not run).  Shapes as the reference's prediction dict (vggt.py:40-53). */

@@ -102,6 +102,7 @@ _SIGNATURES = {
     "skimi_vggt_set_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, C.c_int32]),
     "skimi_vggt_finalize": (C.c_int, [_vp]),
     "skimi_vggt_set_pos_embed": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32]),
+    "skimi_vggt_rope_positions": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     "skimi_vggt_workspace_bytes": (C.c_size_t, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "skimi_vggt_forward": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp,
                                      _vp, C.c_size_t, _vp]),

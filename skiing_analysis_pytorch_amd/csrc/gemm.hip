@@ -20,8 +20,12 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace skimi {
+
+// 0 / 1 environment switch, read once
+#define SKIMI_ENV_FLAG(NAME) ([]() { static const bool v = getenv(NAME) && atoi(getenv(NAME)); return v; }())
 
 // ---- staging helpers ------------------------------------------------------------------
 template <typename T> struct Stage;
@@ -326,6 +330,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     // of a 32x32 tile is 2 rows x 32 consecutive columns = two 128-B segments per wave-instruction,
     // the shape global float atomics run at full rate in (MI355X_MICROARCH.md, global float atomics)
     if (p.splitk > 1) {
+        // splitk_ordered (the fp32-accurate mode): every split stores its partial tile into its own plane of the slab and
+        // the epilogue adds the planes in split order -- the same bits on every run; otherwise one plane and atomics
+        float* dst = p.partial + (p.splitk_ordered ? (long)ks * p.M * p.N : 0l);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -334,7 +341,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     const int n = n0 + wc * WN + j * 32 + l31;
-                    if (m < p.M && n < p.N) atomicAdd(p.partial + (long)m * p.N + n, acc[i][j][r]);
+                    if (m < p.M && n < p.N) {
+                        if (p.splitk_ordered) dst[(long)m * p.N + n] = acc[i][j][r];
+                        else atomicAdd(dst + (long)m * p.N + n, acc[i][j][r]);
+                    }
                 }
         return;
     }
@@ -379,9 +389,16 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue(const GemmArgs p) {
         const int m = (int)(idx / p.N);
         const int n = (int)(idx - (long)m * p.N);
         const RowMap rm = row_map(p, m);
-        const float v = p.partial[idx];
+        float v = p.partial[idx];
         // leave the slab zeroed for the next split-K launch that shares it (no memset per launch)
         p.partial[idx] = 0.f;
+        if (p.splitk_ordered) {   // planes 1 .. splitk-1, added in split order (fixed summation order: run-to-run identical)
+            for (int sk = 1; sk < p.splitk; ++sk) {
+                float* q = p.partial + (long)sk * total + idx;
+                v += *q;
+                *q = 0.f;
+            }
+        }
         store_one(p, rm, n, v);
     }
 }
@@ -461,6 +478,7 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     a.rec_row = (long)(d->N / 32) * 64;
     a.partial = nullptr;
     a.f16 = d->prec == SKIMI_PREC_F16;
+    a.splitk_ordered = 0;
     {
         auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
         const bool out_ok = d->out_dtype == SKIMI_F32 ? al16(d->out) : (((uintptr_t)d->out & 7) == 0);
@@ -513,19 +531,27 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
     const long tiles = (long)a.ntm * a.ntn;
     int splitk = 1;
     const int nkt = (int)cdiv(d->K, BK);
+    // fp32-accurate mode: a fixed summation order over the K splits (one slab plane per split, added in order by the
+    // epilogue) instead of global float atomics, whose arrival order changes the last bits from run to run (VERDICT r2
+    // weak 4).  SKIMI_SPLITK_ATOMIC=1: atomics in every mode (A/B timing).
+    bool ordered = d->prec == SKIMI_PREC_BF16X3 && !SKIMI_ENV_FLAG("SKIMI_SPLITK_ATOMIC");
+    const size_t plane = (size_t)d->M * d->N * sizeof(float);
     if (force_splitk > 0) {
         splitk = force_splitk;
-    } else if (tiles < 192 && nkt >= 8 && scratch != nullptr &&
-               (size_t)d->M * d->N * sizeof(float) <= scratch_bytes) {
+        if (ordered && plane * (size_t)splitk > scratch_bytes) ordered = false;   // a pinned split count (tests) on a one-plane slab
+    } else if (tiles < 192 && nkt >= 8 && scratch != nullptr && plane <= scratch_bytes) {
         splitk = (int)std::min<long>(cdiv(512, tiles), nkt / 4);
+        // one plane per split: as many splits as the slab holds (fewer than two: no split at all, never atomics)
+        if (ordered) splitk = (int)std::min<size_t>((size_t)splitk, scratch_bytes / plane);
         if (splitk < 1) splitk = 1;
     }
     int kper = (int)cdiv(nkt, splitk) * BK;
     splitk = (int)cdiv(d->K, kper);
     a.splitk = splitk;
     a.k_per_split = kper;
+    a.splitk_ordered = ordered && splitk > 1;
     if (splitk > 1) {
-        size_t need = (size_t)d->M * d->N * sizeof(float);
+        size_t need = plane * (a.splitk_ordered ? (size_t)splitk : 1);
         if (scratch == nullptr || need > scratch_bytes) {
             set_error("skimi_gemm: split-K scratch too small (%zu needed, %zu given)", need, scratch_bytes);
             return SKIMI_ERR_WORKSPACE;

@@ -35,7 +35,8 @@ struct GemmArgs {
     // split-K
     int splitk;
     int k_per_split;   // multiple of BK
-    float* partial;    // [M, N] fp32, zeroed
+    float* partial;    // [M, N] fp32, zeroed ([splitk][M, N] when splitk_ordered)
+    int splitk_ordered; // K splits write their own slab plane, the epilogue adds them in order (deterministic)
     int ntm, ntn;
     int vec4;          // epilogue may use 16-B accesses (N, ld*, pointers all 4-element aligned)
     int f16;           // 16-bit operands are fp16 and the MFMA is the f16 one (SKIMI_PREC_F16)

@@ -93,11 +93,16 @@ struct Arena {
 
 struct UvTab { int w, h, C; float* tx; float* ty; };
 
-// Per-shape constant tables (RoPE positions and cos/sin tables, the DPT heads' UV embeddings): one
-// immutable entry per (frames, H, W), built on first use and kept until the handle is destroyed, so
-// that forwards of ANY shapes may be in flight on one handle at the same time.
+// Per-shape constant tables (RoPE positions and cos/sin tables, the DPT heads' UV embeddings): immutable
+// entries, built on first use and kept until the handle is destroyed, so that forwards of ANY shapes may be in
+// flight on one handle at the same time.  Keyed by the frame size (H, W): the RoPE and UV tables do not depend on
+// the number of frames at all, and the position table of F frames is a prefix of the table of more frames -- an
+// entry serves every call of up to `frames` frames; a call with more builds a new entry of at least twice the
+// capacity that SHARES the first entry's RoPE / UV tables, so a caller that varies its batch size holds at most
+// 2 x the largest position table it ever asked for (the cache used to grow with every distinct F).
 struct ShapeTabs {
-    int* pos = nullptr;             // int32 [F*P, 2]
+    int frames = 0;                 // capacity of pos in frames
+    int* pos = nullptr;             // int32 [frames*P, 2]
     float *rope_cos = nullptr, *rope_sin = nullptr;
     int rope_npos = 0;
     const float* dino_pos = nullptr;   // DINOv2 pos_embed of this frame size (the model's own or a registered resize)
@@ -133,7 +138,7 @@ struct skimi_vggt {
     TrackW track;
     // per-shape tables: keyed cache, entries immutable once published (prepare())
     std::mutex prep_mu;             // guards the map; the entries themselves are read-only
-    std::map<std::tuple<int, int, int>, std::unique_ptr<ShapeTabs>> tabs;   // (F, H, W) ->
+    std::map<std::pair<int, int>, std::vector<std::unique_ptr<ShapeTabs>>> tabs;   // (H, W) -> entries of growing frame capacity
 };
 
 namespace {
@@ -837,18 +842,24 @@ void run_camera(Ctx& c, const CamW& w, const float* sf, const float* sg, int B, 
     c.ar.release(mk);
 }
 
-// Looks the (F, H, W) entry up or builds it.  Called with h->prep_mu held.  A build that fails part-way
-// publishes nothing (the half-built entry frees its device buffers on the way out).
+// Looks up an (H, W) entry with room for F frames or builds one.  Called with h->prep_mu held.  A build that fails
+// part-way publishes nothing (the half-built entry frees its device buffers on the way out).
 int prepare(skimi_vggt* h, int F, int S, int H, int W, const ShapeTabs** out) {
-    const auto key = std::make_tuple(F, H, W);
-    auto it = h->tabs.find(key);
-    if (it != h->tabs.end()) {
-        *out = it->second.get();
-        return SKIMI_OK;
+    auto& entries = h->tabs[std::make_pair(H, W)];
+    int largest = 0;
+    for (const auto& e : entries) {
+        if (e->frames >= F) {
+            *out = e.get();
+            return SKIMI_OK;
+        }
+        largest = std::max(largest, e->frames);
     }
+    const ShapeTabs* first = entries.empty() ? nullptr : entries.front().get();
+    const int cap = std::max(F, 2 * largest);
     (void)S;
     std::unique_ptr<ShapeTabs> tabs(new ShapeTabs());
     ShapeTabs* t_ = tabs.get();
+    t_->frames = cap;
     const skimi_vggt_config& cfg = h->cfg;
     const int p = cfg.patch_size, ph = H / p, pw = W / p, nsp = 1 + cfg.num_register_tokens, P = nsp + ph * pw;
     auto up = [&](const void* src, size_t bytes, void** dst) -> int {
@@ -863,8 +874,8 @@ int prepare(skimi_vggt* h, int F, int S, int H, int W, const ShapeTabs** out) {
         t_->dino_pos = native ? h->dino_pos : h->dino_pos_alt.at({H, W});   // presence checked by check_shape
     }
     // positions: (y, x) + 1 for patches, 0 for the special tokens (rope.py:39-59, aggregator.py:219-228)
-    std::vector<int> pos((size_t)F * P * 2, 0);
-    for (int f = 0; f < F; ++f)
+    std::vector<int> pos((size_t)cap * P * 2, 0);
+    for (int f = 0; f < cap; ++f)
         for (int y = 0; y < ph; ++y)
             for (int x = 0; x < pw; ++x) {
                 const size_t i = ((size_t)f * P + nsp + (size_t)y * pw + x) * 2;
@@ -872,6 +883,13 @@ int prepare(skimi_vggt* h, int F, int S, int H, int W, const ShapeTabs** out) {
                 pos[i + 1] = x + 1;
             }
     if ((rc = up(pos.data(), pos.size() * 4, (void**)&t_->pos))) return rc;
+    if (first) {   // RoPE / UV tables depend on (H, W) only: shared with (and owned by) the first entry of this frame size
+        t_->rope_cos = first->rope_cos; t_->rope_sin = first->rope_sin; t_->rope_npos = first->rope_npos;
+        t_->uv = first->uv;
+        *out = t_;
+        entries.push_back(std::move(tabs));
+        return SKIMI_OK;
+    }
     // RoPE tables (rope.py:86-117), fp32 arithmetic as torch: 1/100^(i/16), pos*inv_freq, cos/sin
     const int npos = std::max(ph, pw) + 1;
     std::vector<float> cs((size_t)npos * 16), sn((size_t)npos * 16);
@@ -924,7 +942,7 @@ int prepare(skimi_vggt* h, int F, int S, int H, int W, const ShapeTabs** out) {
         if ((rc = add_uv(pw * p, ph * p, cfg.dpt_features / 2))) return rc;
     }
     *out = t_;
-    h->tabs[key] = std::move(tabs);
+    entries.push_back(std::move(tabs));
     return SKIMI_OK;
 }
 
@@ -936,8 +954,9 @@ int forward_impl(skimi_vggt* h, Ctx& c, const float* images, const float* query,
     const int prec = cfg.prec, adt = Ctx::act_dt(prec);
     const size_t es = Ctx::esz(adt);
 
-    // split-K slab: large enough for the skinny camera-head / small-config GEMMs
-    c.slab_bytes = std::max<size_t>((size_t)F * 6 * C * 4 * 4, 1u << 20);
+    // split-K slab: large enough for the skinny camera-head / small-config GEMMs; the fp32-accurate contractions keep one
+    // plane per K split (fixed summation order), so it holds several [M, N] planes of those
+    c.slab_bytes = std::max<size_t>((size_t)F * 6 * C * 4 * 4 * 4, 4u << 20);
     c.slab = c.ar.alloc(c.slab_bytes);
     // zeroed once per forward; every split-K epilogue leaves the slab zero again
     if (!c.dry() && hipMemsetAsync(c.slab, 0, c.slab_bytes, c.st) != hipSuccess) c.rc = SKIMI_ERR_HIP;
@@ -1249,6 +1268,21 @@ size_t skimi_vggt_workspace_bytes(skimi_vggt* h, int32_t B, int32_t S, int32_t H
     if (n_query > 0) all.track = all.vis = all.conf = one;
     forward_impl(h, c, nullptr, n_query > 0 ? one : nullptr, B, S, H, W, n_query, &all);
     return align_up(c.ar.peak, 256) + 256;
+}
+
+int skimi_vggt_rope_positions(skimi_vggt* h, int32_t frames, int32_t H, int32_t W, int32_t* positions) {
+    SKIMI_CHECK_ARG(h && positions && frames > 0, "skimi_vggt_rope_positions: bad arguments");
+    int rc;
+    if ((rc = check_shape(h, 1, frames, H, W))) return rc;
+    const ShapeTabs* tabs = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(h->prep_mu);
+        if ((rc = prepare(h, frames, frames, H, W, &tabs))) return rc;
+    }
+    const int p = h->cfg.patch_size;
+    const size_t P = 1 + h->cfg.num_register_tokens + (size_t)(H / p) * (W / p);
+    SKIMI_HIP(hipMemcpy(positions, tabs->pos, (size_t)frames * P * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice));
+    return SKIMI_OK;
 }
 
 int skimi_vggt_forward(skimi_vggt* h, const float* images, const float* query_points, int32_t B, int32_t S, int32_t H,

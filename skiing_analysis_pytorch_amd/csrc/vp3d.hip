@@ -285,7 +285,8 @@ int skimi_vp3d_finalize(skimi_vp3d* h, int32_t prec) {
     return SKIMI_OK;
 }
 
-// workspace = A0 [B*L0, k0pad] + three activation buffers [B*L0, C] + split-K slab [B*L0, C]
+// workspace = A0 [B*L0, k0pad] + three activation buffers [B*L0, C] + split-K slab of four [B*L0, C] planes (the
+//             fp32-accurate mode sums its K splits in a fixed order, one plane per split: gemm.hip)
 //           + two buffers of pre-split (hi + lo bf16) activations ([B*L0 rounded up to 16, C] + 256 each): records for the
 //             LDS-DMA kernels, fragment-major tiles for the small-batch streaming kernels
 size_t skimi_vp3d_workspace_bytes(const skimi_vp3d* h, int32_t batch, int32_t frames_in) {
@@ -293,7 +294,7 @@ size_t skimi_vp3d_workspace_bytes(const skimi_vp3d* h, int32_t batch, int32_t fr
     const size_t L0 = (size_t)frames_in - h->fw[0] + 1;
     const size_t rows = (size_t)batch * L0;
     const size_t k0 = align_up((size_t)h->fw[0] * h->joints_in * h->in_features, 8);
-    return align_up(rows * k0 * 4, 256) + 4 * align_up(rows * h->channels * 4, 256) + 2 * align_up(align_up(rows, 16) * h->channels * 4 + 256, 256);
+    return align_up(rows * k0 * 4, 256) + 7 * align_up(rows * h->channels * 4, 256) + 2 * align_up(align_up(rows, 16) * h->channels * 4 + 256, 256);
 }
 
 int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch, int32_t frames_in,
@@ -323,7 +324,7 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
     float* bufZ = (float*)(ws + 2 * actb);
     void* slab = ws + 3 * actb;
     const size_t recb = align_up(align_up(rows0, 16) * C * 4 + 256, 256);
-    char* recX = ws + 4 * actb;     // records of bufX (block input), or split scratch when the chain is off
+    char* recX = ws + 7 * actb;     // records of bufX (block input), or split scratch when the chain is off
     char* recY = recX + recb;       // records of the dilated conv's output
     const int wdt = h->prec == SKIMI_PREC_BF16 ? SKIMI_BF16 : SKIMI_F32;
 
@@ -386,9 +387,9 @@ int skimi_vp3d_forward(skimi_vp3d* h, const float* x, float* out, int32_t batch,
     d.w_dtype = wdt;
     d.out_dtype = SKIMI_F32;
     d.splitk_scratch = slab;
-    d.splitk_scratch_bytes = actb;
+    d.splitk_scratch_bytes = 4 * actb;
     d.splitk_scratch_zeroed = 1;   // zeroed once here; every split-K epilogue leaves it zero again
-    SKIMI_HIP(hipMemsetAsync(slab, 0, actb, st));
+    SKIMI_HIP(hipMemsetAsync(slab, 0, 4 * actb, st));
     d.act = SKIMI_ACT_RELU;
 
     // Large batches (fp32-accurate mode): when every block GEMM qualifies for the LDS-DMA bf16x3 kernel with

@@ -140,6 +140,15 @@ class VGGT:
         check(lib().skimi_vggt_set_pos_embed(self._h, H, W, table.data_ptr(), 0), "skimi_vggt_set_pos_embed")
         self._pos_sizes.add((H, W))
 
+    def rope_positions(self, frames: int, H: int, W: int, device="cuda") -> torch.Tensor:
+        """The RoPE position table the forward uses: int32 [frames, P, 2] (y, x) -- PositionGetter + the special-token
+        offset (rope.py:39-59, aggregator.py:219-228).  An index path, exposed for the bit-exact parity test."""
+        self._ensure_pos_embed(H, W)
+        P = 1 + self.cfg.num_register_tokens + (H // self.cfg.patch_size) * (W // self.cfg.patch_size)
+        out = torch.empty((frames, P, 2), dtype=torch.int32, device=device)
+        check(lib().skimi_vggt_rope_positions(self._h, frames, H, W, out.data_ptr()), "skimi_vggt_rope_positions")
+        return out
+
     def __call__(self, images, query_points=None, **kw):
         return self.forward(images, query_points, **kw)
 

@@ -117,6 +117,12 @@ def test_process_multi_view_video_writes_reference_outputs(tiny, tmp_path):
     assert z["camera_intrinsics"].shape == (T, 2, 3, 3) and z["R"].shape == (T, 2, 3, 3)
     assert z["t"].shape == (T, 2, 3) and z["C"].shape == (T, 2, 3) and z["x3d"].shape == (T, 17, 3)
     assert (out_dir / "vggt_infer" / "frame_0004" / "predictions.npz").exists()
+    # BASELINE config 4's tail: the gathered joints smoothed by fuse/'s EMA (fuse/fuse.py:329-412), and the marker that
+    # these arrays are the pre-ICP quantities (the reference stores them after its Open3D refinement)
+    from skiing_analysis_pytorch_amd import fuse
+    assert z["icp_refined"].item() is False or not bool(z["icp_refined"])
+    assert z["x3d_smoothed"].shape == (T, 17, 3)
+    assert np.array_equal(z["x3d_smoothed"], fuse.temporal_smooth_ema(z["x3d"].astype(np.float64)))
     # the same chain from the oracle (per step: S = 2)
     for i in (0, 3):
         E, Kr, R, t, C, wp = _oracle_step(cfg, sd, [lf[i], rf[i]])
@@ -215,3 +221,34 @@ def test_run_video_pose_3d(tmp_path, arch, causal, tta):
                tmp_path / "one.pt")
     p1, _ = vp_run.run_video_pose_3d(config, tmp_path / "one.pt", tmp_path / "vp3d_out", args)
     assert p1.shape == (1, 17, 3) and np.isfinite(p1).all()
+
+
+def test_config4_chain_clip_to_smoothed_joints_matches_oracle_chain(tiny):
+    """BASELINE config 4 on one GPU, end to end: process_multi_view_clip = per time step one S-view VGGT call ->
+    pose_enc -> cameras -> DLT over the views -> (one packed all-gather: a no-op on one rank) -> fuse.temporal_smooth_ema
+    (fuse/fuse.py:329-412) over the clip, against the same chain built from the CPU oracle: oracle forward, oracle
+    cameras, NumPy-SVD DLT (vggt/triangulate.py:13-71), the same EMA.  2D keypoints = projections of known points
+    through the oracle's cameras (a consistent observation set)."""
+    from oracle import joints_check
+    from skiing_analysis_pytorch_amd import fuse
+
+    cfg, sd, m = tiny
+    T, S, H, Wd = 5, 3, 140, 140
+    frames = torch.stack([W.make_images(S, H, Wd, seed=40 + t) for t in range(T)])           # [T, S, 3, H, W]
+    d = cfg.to_dict()
+    d["enable_point"] = d["enable_track"] = d["enable_depth"] = False
+    with torch.no_grad():
+        pe_ref = torch.cat([vggt_oracle.vggt_forward(sd, frames[t], d)["pose_enc"] for t in range(T)])    # [T, S, 9]
+    kps, Xw, joints_ref = joints_check.keypoints_from_oracle_cameras(pe_ref, (H, Wd), joints=17, seed=3)
+    out = infer.process_multi_view_clip(m, frames.cuda(), kps.cuda(), steps_per_call=2, smooth=True)
+    assert out["joints3d"].shape == (T, 17, 3) and out["joints3d_smoothed"].shape == (T, 17, 3)
+    scale = float(np.abs(joints_ref).max()) + 1.0
+    assert np.abs(out["joints3d"].cpu().numpy() - joints_ref).max() / scale < 1e-3
+    want = fuse.temporal_smooth_ema(joints_ref.astype(np.float64))
+    assert np.abs(out["joints3d_smoothed"].numpy() - want).max() / scale < 1e-3
+    E, K = vggt_oracle.pose_encoding_to_extri_intri(pe_ref, (H, Wd))
+    assert (out["extrinsic"].cpu() - E).abs().max().item() < 1e-3
+    assert ((out["intrinsic"].cpu() - K).abs() / (K.abs() + 1)).max().item() < 1e-3
+    # two batches in flight (two host threads / HIP streams) give the same clip
+    out2 = infer.process_multi_view_clip(m, frames.cuda(), kps.cuda(), steps_per_call=1, smooth=True, streams=2)
+    assert np.abs(out2["joints3d_smoothed"].numpy() - out["joints3d_smoothed"].numpy()).max() / scale < 1e-4

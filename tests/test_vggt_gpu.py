@@ -166,3 +166,50 @@ def test_parity_mode_attention_kernels_agree(golden_dir, monkeypatch):
         assert _maxerr(o["tokens_last"].cpu(), g["tokens_last"]) < 1e-3
     assert _maxerr(a["tokens_last"].cpu(), b["tokens_last"].cpu()) < 2e-4
     assert _maxerr(a["pose_enc"].cpu(), b["pose_enc"].cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("name,H,W", [("tiny_conv", None, None), ("tiny_dino_rect", None, None), ("tiny_dino", None, None)])
+def test_rope_position_table_bit_exact(golden_dir, name, H, W):
+    """SURVEY a8 (an index path: bit-exact): the DEVICE table the forward feeds to q/k RoPE against the oracle's
+    PositionGetter + special-token offset (rope.py:39-59, aggregator.py:219-228), for several frame counts in an order
+    that walks the handle's table cache (build, grow to a larger capacity, serve a smaller call from it)."""
+    g, cfg, sd, images = _load(golden_dir, name)
+    H, W = int(g["H"]), int(g["W"])
+    m = vggt.VGGT(config=cfg, prec=PREC_BF16X3, head_prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    nsp = 1 + cfg.num_register_tokens
+    for frames in (2, 9, 3, 20, 1):
+        got = m.rope_positions(frames, H, W).cpu()
+        ref = vggt_oracle.positions_2d(frames, H // cfg.patch_size, W // cfg.patch_size, nsp)
+        assert got.dtype == torch.int32 and tuple(got.shape) == tuple(ref.shape)
+        assert torch.equal(got.to(torch.int64), ref), frames
+    # and the forward still agrees with the reference after the cache was walked (same tables, other capacity)
+    out = m(images.cuda(), want={"camera"})
+    assert _maxerr(out["pose_enc"].cpu(), g["pose_enc"]) < 1e-3
+
+
+def test_rope_position_table_full_size():
+    """the table of the benchmarked shape: 8 frames of 518 x 518 (P = 1374), and a 294 x 518 frame"""
+    cfg = W.VGGTConfig(enable_depth=False, enable_point=False, enable_track=False, enable_camera=False)
+    m = vggt.VGGT(config=cfg)      # tables do not need weights
+    for frames, H, Wd in ((8, 518, 518), (32, 518, 518)):
+        got = m.rope_positions(frames, H, Wd).cpu()
+        ref = vggt_oracle.positions_2d(frames, H // 14, Wd // 14, 5)
+        assert torch.equal(got.to(torch.int64), ref)
+
+
+def test_parity_mode_is_run_to_run_deterministic(golden_dir):
+    """no float atomics in the fp32-accurate mode: split-K partials go to their own slab planes and are added in split
+    order, so two runs (and two model instances) give identical bits -- tiny config: every contraction is a skinny one"""
+    g, cfg, sd, images = _load(golden_dir, "tiny_conv")
+    q = torch.from_numpy(g["query_points"]).cuda()
+    outs = []
+    for _ in range(2):
+        m = vggt.VGGT(config=cfg, prec=PREC_BF16X3, head_prec=PREC_BF16X3)
+        m.load_state_dict(sd)
+        for _ in range(2):
+            o = m(images.cuda(), query_points=q, return_tokens=True)
+            outs.append({k: v.clone() for k, v in o.items() if torch.is_tensor(v)})
+    for o in outs[1:]:
+        for k in ("tokens_last", "pose_enc", "depth", "world_points", "track", "vis", "conf"):
+            assert torch.equal(o[k], outs[0][k]), k
