@@ -286,6 +286,26 @@ def test_joint_and_prediction_writers(tmp_path):
     assert sorted(z.files) == ["depth", "pose_enc"] and z["depth"].shape == (1, 2, 4, 4, 1)
 
 
+def test_3d_joints_writer_matches_the_file_the_reference_wrote(golden_dir, tmp_path):
+    """SURVEY f3 (VERDICT r2 missing 5): tests/golden/formats_3d_joints.npy was written by the reference's own
+    VideoPose3D/save.py:31-61 `save_3d_joints` (tools/make_goldens.py gen_formats) from the arrays beside it.  The build's
+    writer gives the same file byte for byte, and its reader returns what the reference wrote, key for key."""
+    from skiing_analysis_pytorch_amd import formats
+
+    ins = np.load(golden_dir / "formats_3d_joints_inputs.npz")
+    ref_file = golden_dir / "formats_3d_joints.npy"
+    p = formats.save_3d_joints(ins["fused"], ins["left"], ins["right"], tmp_path / "sub" / "joints.npy")
+    assert p.read_bytes() == ref_file.read_bytes()
+    got = formats.load_3d_joints(ref_file)       # a file made in this container by tools/make_goldens.py
+    assert sorted(got) == ["fused_joints_3d", "left_joints_3d", "right_joints_3d"]
+    for k, a in (("fused_joints_3d", ins["fused"]), ("left_joints_3d", ins["left"]), ("right_joints_3d", ins["right"])):
+        assert got[k].shape == a.shape
+        assert np.array_equal(got[k], a.astype(np.float64), equal_nan=True), k
+    assert np.isnan(got["fused_joints_3d"][1, 5]).all() and np.isinf(got["right_joints_3d"][3, 0, 2])
+    with pytest.raises(ValueError):
+        formats.save_3d_joints(ins["fused"], ins["left"], ins["right"], tmp_path / "x.csv", fmt="csv")
+
+
 def test_committed_bench_line_has_the_contract_fields():
     """profiles/r01_bench_line.json is one line of bench.py's output: the driver's contract fields plus the
     `roofline` and `cpu_baseline` objects, internally consistent."""

@@ -355,6 +355,33 @@ def gen_geometry():
 GENERATORS["geometry"] = gen_geometry
 
 
+def gen_formats():
+    """a file written by the reference's OWN writer, VideoPose3D/save.py:31-61 `save_3d_joints` (imports
+    cleanly here: logging, pathlib, numpy) -- the fused / left / right joints of a clip as one `.npy` holding a dict of
+    nested lists -- next to the arrays it was given.  The build's writer (formats.save_3d_joints) must produce the same
+    bytes, its reader the same values.  (vggt/save.py and VideoPose3D/run.py import cv2 / trimesh / omegaconf and cannot
+    be imported: predictions.npz, the camera NPZ and the pose .npy stay pinned by the cited lines only.)"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ref_vp3d_save", os.path.join(REF, "VideoPose3D", "save.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(33)
+    T = 4
+    fused = rng.normal(size=(T, 17, 3))
+    left = rng.normal(size=(T, 17, 3)).astype(np.float32)      # float32 inputs: tolist() widens them to Python floats
+    right = rng.normal(size=(T, 17, 3))
+    fused[1, 5] = np.nan                                       # a missing joint
+    right[3, 0, 2] = np.inf
+    out = GOLD / "formats_3d_joints.npy"
+    mod.save_3d_joints(fused, left, right, out)
+    np.savez(GOLD / "formats_3d_joints_inputs.npz", fused=fused, left=left, right=right)
+    print("wrote", out.name, out.stat().st_size, "bytes (by the reference's save_3d_joints) + its inputs")
+
+
+GENERATORS["formats"] = gen_formats
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENERATORS)
     for w in which:
