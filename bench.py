@@ -408,13 +408,13 @@ def vp3d_leg(dev, cpu=True):
     m.load_state_dict(sd)
     wbytes = sum(v.numel() * 4 for k, v in sd.items() if k.endswith("weight") and v.dim() == 3)
     res = {"model": "TemporalModel RF 27, 1024 channels, bf16x3 (fp32-accurate), 243-frame clips", "hbm_peak_GBps": 8000.0}
-    for B in (1, 64):
+    for B in (1, 2, 64):   # 2 = the call the reference makes: the clip and its flipped copy (flip-TTA, VideoPose3D/run.py:1070-1083)
         x = torch.randn(B, 269, 17, 2, device=dev)     # 243 frames edge-padded by the receptive field (generators.py:216-239)
         out = torch.empty(B, 243, 17, 3, device=dev)
         for _ in range(3):
             m(x, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 50 if B == 1 else 10
+        n = 50 if B <= 2 else 10
         e0.record()
         for _ in range(n):
             m(x, out=out)
@@ -431,7 +431,9 @@ def vp3d_leg(dev, cpu=True):
             res["clips_1"]["traffic_source"] = ("static: profiles/r02_vp3d_traffic.json (rocprofv3 --pmc passes of this kernel source, "
                                                 "matched by its sha256; L2 <-> fabric bytes per call: each layer's 1 MB of activations is "
                                                 "fetched once per XCD from the Infinity Cache; null when the kernel changed since)")
-        if B > 1:
+        if B == 2:
+            res["clips_2"]["note"] = "the reference's own call shape: [clip, flipped clip] in one batch (test-time augmentation)"
+        if B > 2:
             # a batch of clips re-uses every weight B x 243 times: the call is bound by the matrix pipe, not by HBM.
             # 4.31 GFLOP per clip; the fp32-accurate mode issues three bf16 MFMAs per product
             fl = 4.31e9 * B
@@ -445,13 +447,13 @@ def vp3d_leg(dev, cpu=True):
     m5.load_state_dict(sd5)
     wbytes5 = sum(v.numel() * 4 for k, v in sd5.items() if k.endswith("weight") and v.dim() == 3)
     res["rf243"] = {"model": "TemporalModel RF 243 (filter widths 3,3,3,3,3), 1024 channels, bf16x3, 485 -> 243 frames"}
-    for B in (1, 64):
+    for B in (1, 2, 64):
         x = torch.randn(B, 485, 17, 2, device=dev)
         out = torch.empty(B, 243, 17, 3, device=dev)
         for _ in range(3):
             m5(x, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 50 if B == 1 else 5
+        n = 50 if B <= 2 else 5
         e0.record()
         for _ in range(n):
             m5(x, out=out)

@@ -66,6 +66,7 @@ struct DptW {
     unsigned short* oc2a_direct = nullptr;   // conv_direct.hip weight layout of oc2a (fp32-accurate heads)
     int n_out = 0, features = 0, oc[4] = {0, 0, 0, 0};
     bool feature_only = false, pos_embed = true;
+    bool act_f32 = false;   // activations fp32 in memory whatever the MFMA mode (16-bit modes round them while staging)
     int down_ratio = 1;
 };
 struct CamW {
@@ -556,7 +557,7 @@ const UvTab* find_uv(const ShapeTabs* h, int w, int hh, int C) {
 void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, int P, int nsp, int ph, int pw, int C,
               int H, int W, float* pts, float* conf, int act_mode) {
     const int prec = w.proj[0].prec;
-    const int adt = Ctx::act_dt(prec);
+    const int adt = w.act_f32 ? SKIMI_F32 : Ctx::act_dt(prec);
     const size_t es = Ctx::esz(adt);
     const int D = 2 * C, np = ph * pw, feat = w.features;
     const size_t mk = c.ar.mark();
