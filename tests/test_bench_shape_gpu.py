@@ -179,6 +179,31 @@ def test_f16_mode_meets_the_joints_bar_at_bench_shape(bench_shape):
     assert pe < pe16 / 3, (pe, pe16)
 
 
+def test_fp8_mode_forward_at_bench_shape(bench_shape):
+    """BASELINE config 5 (VGGT with e4m3 weights): SKIMI_PREC_FP8 -- MXFP8 qkv / fc1 / fc2 in the 72 blocks -- at VGGT-1B
+    size against the fp32 oracle.  The reference has no fp8 path (parity unpinned: the quantiser is pinned against the
+    OCP formats in test_fp8_gpu.py); this bounds what e4m3's 3 mantissa bits (16x bf16's rounding) do to the outputs:
+    pose_enc ~8e-2 (measured; bf16 5e-3, fp16 7e-4), NOT within the 1e-3 joints bar -- reported separately by bench.py
+    as SURVEY 8(d) asks."""
+    from skiing_analysis_pytorch_amd._lib import PREC_FP8
+
+    s = bench_shape
+    m = vggt.VGGT(config=s["cfg"], prec=PREC_FP8, head_prec=PREC_BF16X3)
+    m.load_state_dict(s["sd"])
+    out = m(s["images"].cuda(), query_points=s["queries"].cuda())
+    torch.cuda.synchronize()
+    ref = s["ref"]
+    for k in ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf", "track", "vis", "conf"):
+        assert out[k].shape == ref[k].shape and torch.isfinite(out[k]).all(), k
+    pe = (out["pose_enc"].cpu() - ref["pose_enc"]).abs().max().item()
+    rel = (out["depth"].cpu() - ref["depth"]).abs() / (ref["depth"].abs() + 1.0)
+    er = _ring_mpjpe(out, s)
+    print(f"fp8 mode: pose_enc max abs err {pe:.3e}, ring-rig MPJPE {er:.3e}, depth rel err median {rel.median().item():.2e}")
+    assert pe < 0.3 and rel.median().item() < 1e-2 and er < 0.3
+    assert (out["pose_enc"][0] - out["pose_enc"][1]).abs().max().item() > 1e-4
+    assert (out["track"].cpu() - ref["track"]).abs().median().item() < 2.0
+
+
 @pytest.mark.parametrize("S_sv", [8, 16])
 def test_single_view_clip_config2(bench_shape, S_sv):
     """BASELINE config 2 (`single_view_process` semantics: every 30th frame of ONE camera forms a single
