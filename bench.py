@@ -144,14 +144,20 @@ def main():
         out = active["model"](images_k, query_points=kps_k[:, 0].contiguous() if track else None, want=want)
         E, K = geometry.pose_encoding_to_extri_intri(out["pose_enc"], (IMG, IMG))
         out["joints3d_local"] = geometry.triangulate_joints(K, E[..., :3, :3].contiguous(), E[..., :3, 3].contiguous(), kps_k)
+        out["E_local"], out["K_local"] = E, K
+        return out
+
+    def gather(out, n_total):
+        # under torch.distributed the per-rank joints AND cameras are re-assembled with the path's ONE collective
+        # (parallel.all_gather_packed: one byte record per time step, all-gather over xGMI), as process_multi_view_clip does
+        if use_dist:
+            out["joints3d"], out["E"], out["K"] = parallel.all_gather_packed([out["joints3d_local"], out["E_local"], out["K_local"]], n_total)
+        else:
+            out["joints3d"], out["E"], out["K"] = out["joints3d_local"], out["E_local"], out["K_local"]
         return out
 
     def step():
-        out = step_on(images, kps)
-        # under torch.distributed the per-rank joints are re-assembled with the path's one collective
-        # (all-gather over xGMI)
-        out["joints3d"] = parallel.all_gather_steps(out["joints3d_local"], world * B) if use_dist else out["joints3d_local"]
-        return out
+        return gather(step_on(images, kps), world * B)
 
     def step_multi(n_streams):
         """one step = n_streams independent batches, each on its own stream from its own host thread: the
@@ -176,11 +182,10 @@ def main():
             t_.join()
         for s_ in side:
             main.wait_stream(s_)
-        joints = torch.cat([o["joints3d_local"] for o in outs])
         out = outs[0]
-        out["joints3d_local"] = joints
-        out["joints3d"] = parallel.all_gather_steps(joints, world * n_streams * B) if use_dist else joints
-        return out
+        for key in ("joints3d_local", "E_local", "K_local"):
+            out[key] = torch.cat([o[key] for o in outs])
+        return gather(out, world * n_streams * B)
 
     step()   # prepares the handle for this frame shape (and is the one-stream warm-up)
     for _ in range(args.warmup):
@@ -219,6 +224,11 @@ def main():
         blocks = out["joints3d"].double().reshape(world, -1).sum(dim=1)
         assert torch.equal(sums, blocks), "all-gather: a rank's block is missing from the gathered joints"
         assert torch.isfinite(out["joints3d"]).all()
+        assert out["E"].shape == (world * nloc, S_VIEWS, 3, 4) and torch.equal(out["E"][rank * nloc:(rank + 1) * nloc], out["E_local"])
+    # BASELINE config 4's last stage on the gathered joints (outside the timed region: it runs once per clip on the host)
+    from skiing_analysis_pytorch_amd import fuse
+    smoothed = fuse.temporal_smooth_ema(out["joints3d"].cpu().numpy().astype("float64"))
+    assert smoothed.shape == tuple(out["joints3d"].shape)
 
     frames = world * args.steps * B * NS
     value = frames / elapsed
