@@ -266,7 +266,7 @@ def main():
         line["roofline"] = {"kernel": "attn_q64_kernel (global attention, seq 10992, 16 heads x 64)",
                             "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(B),
-                            "traffic_source": "static: profiles/r02_attn_traffic.json (rocprofv3 --pmc passes of this kernel "
+                            "traffic_source": "static: profiles/r03_attn_traffic.json (rocprofv3 --pmc passes of this kernel "
                                               "source, matched by its sha256; null when the kernel changed since)",
                             "avg_launch_us": avg_s * 1e6, "launches": int(n.value),
                             "flops_per_launch": flops_per_launch}
@@ -459,7 +459,7 @@ def vp3d_leg(dev, cpu=True):
                              "frac_of_hbm_peak": alg / t / 8e12}
         if B == 1:
             res["clips_1"]["traffic"] = vp3d_traffic()
-            res["clips_1"]["traffic_source"] = ("static: profiles/r02_vp3d_traffic.json (rocprofv3 --pmc passes of this kernel source, "
+            res["clips_1"]["traffic_source"] = ("static: profiles/r03_vp3d_traffic.json (rocprofv3 --pmc passes of this kernel source, "
                                                 "matched by its sha256; L2 <-> fabric bytes per call: each layer's 1 MB of activations is "
                                                 "fetched once per XCD from the Infinity Cache; null when the kernel changed since)")
         if B == 2:
@@ -515,7 +515,7 @@ def vp3d_traffic():
     import hashlib
     root = Path(__file__).resolve().parent
     try:
-        d = json.loads((root / "profiles" / "r02_vp3d_traffic.json").read_text())
+        d = json.loads((root / "profiles" / "r03_vp3d_traffic.json").read_text())
         sha = hashlib.sha256((root / "skiing_analysis_pytorch_amd" / "csrc" / "vp3d_stream.hip").read_bytes()).hexdigest()[:16]
     except (OSError, ValueError):
         return None
@@ -539,10 +539,10 @@ def attn_kernel_sha():
 
 def pmc_traffic(time_steps):
     """HBM bytes per global-attention launch from the committed rocprofv3 PMC passes
-    (profiles/r02_attn_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/pmc_traffic.py).  A static
+    (profiles/r03_attn_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, tools/pmc_traffic.py).  A static
     figure, not measured in this run: returned only when the profile was taken at this launch shape AND
     on this kernel source (sha256 recorded in the file), otherwise None."""
-    f = Path(__file__).resolve().parent / "profiles" / "r02_attn_traffic.json"
+    f = Path(__file__).resolve().parent / "profiles" / "r03_attn_traffic.json"
     try:
         d = json.loads(f.read_text())
     except (OSError, ValueError):

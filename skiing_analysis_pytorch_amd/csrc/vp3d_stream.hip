@@ -300,11 +300,15 @@ struct Vp3dConv {
 // XF32 = 1: the activation operand is the raw fp32 input [B * Lin][xstride] (the 2D keypoints): row l's K vector is
 // the `kvalid` consecutive floats starting at row l (= the taps x Cin window of expand_conv, model.py:103), split
 // into hi + lo in registers; C is K rounded up to a multiple of 32.
-template <int CT, int RT, int TAPS, int XF32 = 0>
-__global__ __launch_bounds__(512) void vp3d_conv_kernel(const Vp3dConv p) {
+// NW = waves per workgroup: 8 (K split over eight waves, one workgroup per CU: 120 KiB of K-partials for the dilated convs),
+// or 4 -- half the partials, so TWO workgroups share a CU.  A launch of 257 .. 512 workgroups (a batch of two clips: the
+// reference's own call, a clip and its flipped copy, VideoPose3D/run.py:1070-1083) then runs as ONE round of co-resident
+// pairs that pay the in-kernel fixed cost (first loads out, K-partials, store drain: 4-9 us) once, instead of two rounds.
+template <int CT, int RT, int TAPS, int XF32 = 0, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void vp3d_conv_kernel(const Vp3dConv p) {
     constexpr int TA = CT / 16, D = 2, NTL = TAPS * TA * RT;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);          // [8 waves][NTL tiles][64 lanes]
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);          // [NW waves][NTL tiles][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kg = lane >> 4;
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(512) void vp3d_conv_kernel(const Vp3dConv p) {
     const int b = rem / p.msc, rs = rem - b * p.msc;
     const int c0 = ct * CT, l0 = rs * p.R;
     const int SC = p.C >> 5;
-    const int cs0 = (int)((long)wave * SC / 8), cs1 = (int)((long)(wave + 1) * SC / 8);
+    const int cs0 = (int)((long)wave * SC / NW), cs1 = (int)((long)(wave + 1) * SC / NW);
     const int ncs = cs1 - cs0;
     const int rot = ncs > 0 ? ((blockIdx.x >> 3) * 3) % ncs : 0;
     auto slice_at = [&](int i) {
@@ -423,11 +427,11 @@ __global__ __launch_bounds__(512) void vp3d_conv_kernel(const Vp3dConv p) {
 #pragma unroll
             for (int j = 0; j < RT; ++j) red[(wave * NTL + (t * TA + a) * RT + j) * 64 + lane] = acc[t][a][j];
     __syncthreads();
-    // out[l0 + m][c0 + 16 a + 4 q .. +3] = sum over taps and the 8 K-partials of P_t[m + t d]; the accumulator of
+    // out[l0 + m][c0 + 16 a + 4 q .. +3] = sum over taps and the NW K-partials of P_t[m + t d]; the accumulator of
     // row rho, channel quad q of a 16 x 16 tile sits in lane (rho & 15) + 16 q of row tile rho >> 4
     constexpr int Q = CT / 4;
     const int rv = min(p.R, p.Lout - l0);
-    for (int o = tid; o < rv * Q; o += 512) {
+    for (int o = tid; o < rv * Q; o += 64 * NW) {
         const int m = o / Q, q = o - m * Q;
         const int a = q >> 2, kq = q & 3;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(512) void vp3d_conv_kernel(const Vp3dConv p) {
             const int rho = m + t * p.dil;
             const int idx = ((t * TA + a) * RT + (rho >> 4)) * 64 + (rho & 15) + 16 * kq;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 const f32x4 u = red[w * NTL * 64 + idx];
                 v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
             }
@@ -480,12 +484,13 @@ __global__ __launch_bounds__(512) void vp3d_conv_kernel(const Vp3dConv p) {
     }
 }
 
-template <int CT, int RT, int TAPS, int XF32 = 0>
+template <int CT, int RT, int TAPS, int XF32 = 0, int NW = 8>
 static int launch_conv(const Vp3dConv& p, int grid, hipStream_t st) {
-    constexpr int lds = 8 * TAPS * (CT / 16) * RT * 1024;
+    constexpr int lds = NW * TAPS * (CT / 16) * RT * 1024;
+    static_assert(lds <= (NW == 4 ? 80 : 160) * 1024, "K-partials must fit the LDS (two workgroups per CU at NW = 4)");
     if (lds > 64 * 1024)   // > 64 KiB of dynamic LDS needs the opt-in, once per kernel and device
-        SKIMI_LDS_OPT_IN((vp3d_conv_kernel<CT, RT, TAPS, XF32>), lds, "vp3d_conv");
-    hipLaunchKernelGGL((vp3d_conv_kernel<CT, RT, TAPS, XF32>), dim3(grid), dim3(512), lds, st, p);
+        SKIMI_LDS_OPT_IN((vp3d_conv_kernel<CT, RT, TAPS, XF32, NW>), lds, "vp3d_conv");
+    hipLaunchKernelGGL((vp3d_conv_kernel<CT, RT, TAPS, XF32, NW>), dim3(grid), dim3(64 * NW), lds, st, p);
     return SKIMI_OK;
 }
 
@@ -497,7 +502,7 @@ int vp3d_expand_mfma_launch(const float* x, const void* wfrag, int Kpad, const f
     const int nt = C / 32;
     int msc = (int)std::max<long>(1, 256 / std::max<long>(1, (long)nt * B));
     msc = std::min(msc, Lout);
-    while (cdiv(cdiv(Lout, msc), 16) > 4) ++msc;
+    while (cdiv(cdiv(Lout, msc), 16) > 5) ++msc;
     Vp3dConv q;
     q.wrec = (const char*)wfrag; q.xrec = (const char*)x; q.bias = bias; q.resid = nullptr;
     q.out_f32 = out_f32; q.out_rec = (char*)out_rec;
@@ -510,7 +515,8 @@ int vp3d_expand_mfma_launch(const float* x, const void* wfrag, int Kpad, const f
     if (rt == 1) rc = launch_conv<32, 1, 1, 1>(q, grid, st);
     else if (rt == 2) rc = launch_conv<32, 2, 1, 1>(q, grid, st);
     else if (rt == 3) rc = launch_conv<32, 3, 1, 1>(q, grid, st);
-    else rc = launch_conv<32, 4, 1, 1>(q, grid, st);
+    else if (rt == 4) rc = launch_conv<32, 4, 1, 1>(q, grid, st);
+    else rc = launch_conv<32, 5, 1, 1>(q, grid, st);
     if (rc) return rc;
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
@@ -610,21 +616,33 @@ int vp3d_mm_launch(const void* wrec, int Npad, const void* xrec, const float* bi
     // First choice: vp3d_conv_kernel (activations loaded once for all taps).  Candidates: taps = 1 -> CT 16 or 32, up to
     // 4 row tiles; taps = 3 -> CT 16, up to 5 row tiles INCLUDING the 2 d halo.  Cost = bytes a workgroup loads x rounds.
     static const int use_conv = getenv("SKIMI_VP3D_TAPREUSE") ? atoi(getenv("SKIMI_VP3D_TAPREUSE")) : 1;
-    int cv_ct = 0, cv_msc = 0, cv_rt = 0;
+    static const int use_pairs = getenv("SKIMI_VP3D_PAIRS") ? atoi(getenv("SKIMI_VP3D_PAIRS")) : 1;   // 0: 8-wave workgroups only (A/B timing)
+    // cost of a candidate = rounds x (elements the workgroups of one CU load in a round + FIXED), FIXED = the in-kernel fixed cost
+    // of a round (first loads out, K-partials through LDS, store drain: ~8 us against ~5.5 us for 131 K elements,
+    // profiles/r02_vp3d_summary.md).  4-wave workgroups sit two to a CU: a round holds 512 of them and loads twice the elements.
+    const double FIXED = 200e3;
+    int cv_ct = 0, cv_msc = 0, cv_rt = 0, cv_nw = 8;
     double cv_cost = 1e30;
     if (use_conv && (taps == 1 || taps == 3)) {
-        for (int ct : {16, 32}) {
-            if (Npad % ct || (taps == 3 && ct != 16)) continue;
-            const int nt = Npad / ct, rtmax = taps == 3 ? 5 : 4;
-            if (halo + 1 > 16 * rtmax) continue;
-            int msc = (int)std::max<long>(1, 256 / std::max<long>(1, (long)nt * B));
-            msc = std::min(msc, Lout);
-            while (cdiv(cdiv(Lout, msc) + halo, 16) > rtmax) ++msc;
-            const int R = (int)cdiv(Lout, msc), rt = (int)cdiv(R + halo, 16);
-            const double rounds = (double)cdiv((long)nt * B * msc, 256);
-            const double cost = rounds * ((double)ct * K + (double)rt * 16 * C);
-            if (cost < cv_cost) {
-                cv_cost = cost; cv_ct = ct; cv_msc = msc; cv_rt = rt;
+        for (int nw : {8, 4}) {
+            if (nw == 4 && !use_pairs) continue;
+            for (int ct : {16, 32}) {
+                if (Npad % ct || (taps == 3 && ct != 16)) continue;
+                const int nt = Npad / ct, rtmax = 5;
+                if (halo + 1 > 16 * rtmax) continue;
+                const long cap = nw == 4 ? 512 : 256;
+                int msc = (int)std::max<long>(1, cap / std::max<long>(1, (long)nt * B));
+                msc = std::min(msc, Lout);
+                while (cdiv(cdiv(Lout, msc) + halo, 16) > rtmax) ++msc;
+                const int R = (int)cdiv(Lout, msc), rt = (int)cdiv(R + halo, 16);
+                if (nw == 4 && taps * (ct / 16) * rt * 4 > 80) continue;   // K-partials of a pair: 2 x (4 waves x tiles) KiB <= 160
+                const long grid = (long)nt * B * msc;
+                const double rounds = (double)cdiv(grid, cap);
+                const double per_cu = nw == 4 ? std::min<double>(2.0, (double)grid / 256.0) : 1.0;   // workgroups a CU runs side by side
+                const double cost = rounds * (std::max(1.0, per_cu) * ((double)ct * K + (double)rt * 16 * C) + FIXED);
+                if (cost < cv_cost || (use_pairs == 2 && nw == 4 && cv_nw == 8)) {   // use_pairs 2: pairs wherever they fit (experiments)
+                    cv_cost = cost; cv_ct = ct; cv_msc = msc; cv_rt = rt; cv_nw = nw;
+                }
             }
         }
     }
@@ -641,7 +659,7 @@ int vp3d_mm_launch(const void* wrec, int Npad, const void* xrec, const float* bi
             R = (int)cdiv(M, ms);
         }
         const double rounds = (double)cdiv((long)nt * ms, 256);
-        const double cost = rounds * ((double)ct * K + (double)taps * cdiv(R, 16) * 16 * C);   // every tap re-reads its row tiles
+        const double cost = rounds * ((double)ct * K + (double)taps * cdiv(R, 16) * 16 * C + FIXED);   // every tap re-reads its row tiles
         if (cost < best) {
             best = cost; best_ct = ct; best_ms = ms; best_rt = (int)cdiv(R, 16);
         }
@@ -656,10 +674,13 @@ int vp3d_mm_launch(const void* wrec, int Npad, const void* xrec, const float* bi
         q.xstride = 0; q.kvalid = 0;
         const int grid = (Npad / cv_ct) * B * cv_msc;
         int rc = SKIMI_ERR_ARG;
-#define SKIMI_VP3D_CONV(CT, RT, TAPS) if (cv_ct == CT && cv_rt == RT && taps == TAPS) rc = launch_conv<CT, RT, TAPS>(q, grid, st); else
+#define SKIMI_VP3D_CONV(CT, RT, TAPS)                                                                   \
+    if (cv_ct == CT && cv_rt == RT && taps == TAPS)                                                     \
+        rc = cv_nw == 4 ? launch_conv<CT, RT, TAPS, 0, 4>(q, grid, st) : launch_conv<CT, RT, TAPS>(q, grid, st); \
+    else
         SKIMI_VP3D_CONV(16, 1, 3) SKIMI_VP3D_CONV(16, 2, 3) SKIMI_VP3D_CONV(16, 3, 3) SKIMI_VP3D_CONV(16, 4, 3) SKIMI_VP3D_CONV(16, 5, 3)
-        SKIMI_VP3D_CONV(16, 1, 1) SKIMI_VP3D_CONV(16, 2, 1) SKIMI_VP3D_CONV(16, 3, 1) SKIMI_VP3D_CONV(16, 4, 1)
-        SKIMI_VP3D_CONV(32, 1, 1) SKIMI_VP3D_CONV(32, 2, 1) SKIMI_VP3D_CONV(32, 3, 1) SKIMI_VP3D_CONV(32, 4, 1)
+        SKIMI_VP3D_CONV(16, 1, 1) SKIMI_VP3D_CONV(16, 2, 1) SKIMI_VP3D_CONV(16, 3, 1) SKIMI_VP3D_CONV(16, 4, 1) SKIMI_VP3D_CONV(16, 5, 1)
+        SKIMI_VP3D_CONV(32, 1, 1) SKIMI_VP3D_CONV(32, 2, 1) SKIMI_VP3D_CONV(32, 3, 1) SKIMI_VP3D_CONV(32, 4, 1) SKIMI_VP3D_CONV(32, 5, 1)
         { set_error("vp3d_conv: unsupported tiling %d x %d x %d", cv_ct, cv_rt, taps); }
 #undef SKIMI_VP3D_CONV
         if (rc) return rc;

@@ -114,7 +114,9 @@ def test_vp3d_small_batches_on_the_streaming_path(fw, causal, monkeypatch):
     m = vp3d.TemporalModel(17, 2, 17, fw, causal=causal, prec=PREC_BF16X3)
     m.load_state_dict(sd)
     rf = m.receptive_field()
-    for B, frames in ((1, rf), (1, rf + 242), (3, rf + 100), (5, rf + 17)):
+    # B = 2 (the reference's flip-TTA call), 4, 6: the dilated convs of launches of 257 .. 512 workgroups run as co-resident
+    # pairs of 4-wave workgroups (vp3d_stream.hip: NW = 4); 5 row tiles per workgroup for the 1 x 1 convs
+    for B, frames in ((1, rf), (1, rf + 242), (2, rf + 242), (2, rf + 57), (3, rf + 100), (4, rf + 242), (5, rf + 17), (6, rf + 130)):
         x = torch.randn(B, frames, 17, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(B * 7 + frames))
         out = m(x)
         assert out.shape == (B, frames - rf + 1, 17, 3)
