@@ -329,6 +329,40 @@ def test_committed_bench_line_has_the_contract_fields():
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
 
 
+def test_round3_bench_line_reports_the_bar():
+    """profiles/r03_bench_line.json (one default `python bench.py` run on an MI355X): the contract fields, the headline mode
+    judged against north_star's bar on the 3D joints (`within_bar` / `value_within_bar` at the top level), every
+    mode's MPJPE on the ring rig and the native scene, and internal consistency of the roofline object."""
+    import json
+    from pathlib import Path
+
+    line = json.loads((Path(__file__).resolve().parent.parent / "profiles" / "r03_bench_line.json").read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "within_bar", "value_within_bar", "mode_within_bar"):
+        assert k in line, k
+    assert line["unit"] == "frames/s" and line["dtype"] == "f16" and line["vs_baseline"] is None and "workload" in line["config"]
+    cfg = line["config"]
+    frames_per_step = cfg["time_steps_per_call"] * cfg.get("streams", 1) * line["n_gpus"]
+    assert abs(line["value"] - frames_per_step / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    mp = line["mpjpe_vs_cpu_oracle"]
+    assert mp["bar"] == 1e-3
+    for mode in ("f16_mode", "bf16_mode", "fp8_mode", "bf16x3_parity_mode"):
+        r = mp[mode]
+        assert r["within_bar"] == (r["mpjpe_ring_rig"] <= 1e-3) and r["within_bar_native_scene"] == (r["mpjpe_native_scene"] <= 1e-3)
+    # the timed mode is inside the bar, so the headline IS the within-bar value; bf16 and fp8 are not, bf16x3 is
+    assert line["within_bar"] is True and mp["f16_mode"]["within_bar"] and line["value_within_bar"] == line["value"]
+    assert line["mode_within_bar"] == "f16"
+    assert not mp["bf16_mode"]["within_bar"] and not mp["fp8_mode"]["within_bar"] and mp["bf16x3_parity_mode"]["within_bar"]
+    assert mp["f16_mode"]["pose_enc_max_abs_err"] < mp["bf16_mode"]["pose_enc_max_abs_err"] / 3
+    rf = line["roofline"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["traffic"] is not None
+    assert abs(rf["achieved"] - rf["flops_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e12) < 1e-6 * rf["achieved"]
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert line["parity_mode"]["steps"] >= 10          # ADVICE r2: the parity leg is timed over >= 10 steps
+    assert "clips_2" in line["vp3d"]                   # the reference's flip-TTA call shape
+
+
 def test_mxfp8_oracle_known_answers():
     """The oracle's e4m3fn / E8M0 arithmetic against the formats' published constants (OCP OFP8 rev 1.0: bias 7, max
     448 = 0x7E, min normal 2^-6 = 0x08, min subnormal 2^-9 = 0x01, 0x7F NaN; MX v1.0: E8M0 value 2^(byte - 127))."""
