@@ -87,6 +87,11 @@ __device__ __forceinline__ unsigned short f2x16(float x, bool f16) {
     const unsigned short a = f2h(x), b = f2bf(x);
     return f16 ? a : b;
 }
+// 16-bit activation element of either format -> fp32 (no branch: both conversions, one select)
+__device__ __forceinline__ float x16tof(unsigned short b, bool f16) {
+    const float a = h2f(b), c = bf2f(b);
+    return f16 ? a : c;
+}
 // one k-step of a 32x32 output tile on 16-bit operands: fp16 (F16) or bf16 fragments, fp32 accumulate
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 template <bool F16>

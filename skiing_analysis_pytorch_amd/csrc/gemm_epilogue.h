@@ -14,7 +14,7 @@ struct GemmArgs {
     int cN, cH, cW, cC, KH, KW, stride, pad, dil, OH, OW;
     const float* bias;
     const float* gamma;
-    const void* resid;     // f32 or bf16 (resid_dtype)
+    const void* resid;     // f32, bf16 or fp16 (resid_dtype)
     int resid_dtype;
     long ldr;
     int resid_rpb;
@@ -115,13 +115,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 __device__ __forceinline__ float load_res(const void* r, int dt, long i) {
-    return dt == SKIMI_F32 ? ((const float*)r)[i] : bf2f(((const unsigned short*)r)[i]);
+    return dt == SKIMI_F32 ? ((const float*)r)[i] : x16tof(((const unsigned short*)r)[i], dt == SKIMI_F16);
 }
 __device__ __forceinline__ float4 load_res4(const void* r, int dt, long i) {
     if (dt == SKIMI_F32) return *reinterpret_cast<const float4*>((const float*)r + i);
     const bf16x4 v = *reinterpret_cast<const bf16x4*>((const unsigned short*)r + i);
-    return make_float4(bf2f((unsigned short)v[0]), bf2f((unsigned short)v[1]), bf2f((unsigned short)v[2]),
-                       bf2f((unsigned short)v[3]));
+    const bool h = dt == SKIMI_F16;
+    return make_float4(x16tof((unsigned short)v[0], h), x16tof((unsigned short)v[1], h), x16tof((unsigned short)v[2], h),
+                       x16tof((unsigned short)v[3], h));
 }
 
 // everything that depends only on the output row m

@@ -66,7 +66,7 @@ struct DptW {
     unsigned short* oc2a_direct = nullptr;   // conv_direct.hip weight layout of oc2a (fp32-accurate heads)
     int n_out = 0, features = 0, oc[4] = {0, 0, 0, 0};
     bool feature_only = false, pos_embed = true;
-    bool act_f32 = false;   // activations fp32 in memory whatever the MFMA mode (16-bit modes round them while staging)
+    bool out_f32 = false;   // feature_only heads: the returned feature map is fp32 whatever the activation format (the tracker reads fp32)
     int down_ratio = 1;
 };
 struct CamW {
@@ -557,7 +557,7 @@ const UvTab* find_uv(const ShapeTabs* h, int w, int hh, int C) {
 void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, int P, int nsp, int ph, int pw, int C,
               int H, int W, float* pts, float* conf, int act_mode) {
     const int prec = w.proj[0].prec;
-    const int adt = w.act_f32 ? SKIMI_F32 : Ctx::act_dt(prec);
+    const int adt = Ctx::act_dt(prec);
     const size_t es = Ctx::esz(adt);
     const int D = 2 * C, np = ph * pw, feat = w.features;
     const size_t mk = c.ar.mark();
@@ -768,10 +768,11 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
             c.rc = conv_direct_n32_launch(rec, rec + f2, w.oc2a_direct, w.oc2a.lin.b, (float*)c2, F, Ho, Wo, f2, 1, c.st,
                                           2L * f2);
     } else {
-        void* c1u = c.ar.alloc((size_t)F * Ho * Wo * f2 * es);
+        const int udt = (w.feature_only && w.out_f32) ? SKIMI_F32 : adt;   // the tracker's feature map: fp32 out of the last upsample
+        void* c1u = c.ar.alloc((size_t)F * Ho * Wo * f2 * Ctx::esz(udt));
         // upsample to the output size with the UV positional embedding added in the same pass
         if (!c.rc && !c.dry())
-            c.rc = bilinear_ac_launch(c1, c1u, adt, F, h1, w1, Ho, Wo, f2, c.st, uvt ? uvt->tx : nullptr, uvt ? uvt->ty : nullptr);
+            c.rc = bilinear_ac_launch(c1, c1u, adt, F, h1, w1, Ho, Wo, f2, c.st, uvt ? uvt->tx : nullptr, uvt ? uvt->ty : nullptr, udt);
         if (w.feature_only) return c1u;   // caller releases the arena
         c2 = c.ar.alloc((size_t)F * Ho * Wo * 32 * es);
         auto d = c.desc(w.oc2a.lin, c1u, adt, f2, F * Ho * Wo, c2, adt, 32);

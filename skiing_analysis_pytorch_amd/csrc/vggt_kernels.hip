@@ -89,11 +89,12 @@ int special_tokens_launch(float* x, const float* table, int F, int S, int P, int
 //   scale = (in-1)/(out-1) (float), src = scale*dst, i0 = min(int(src), in-1), i1 = min(i0+1, in-1),
 //   l1 = clamp(src - i0, 0, 1), out = l0y*(l0x*p00 + l1x*p01) + l1y*(l0x*p10 + l1x*p11)
 // ---------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ in, T* __restrict__ out, int N,
+// T / TO: element type of the input / output map (float, or unsigned short = a 16-bit format: bf16, or fp16 when f16 is set)
+template <typename T, typename TO = T>
+__global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ in, TO* __restrict__ out, int N,
                                                           int h, int w, int H, int W, int C,
                                                           const float* __restrict__ tabx,
-                                                          const float* __restrict__ taby) {
+                                                          const float* __restrict__ taby, bool f16 = false) {
     // one output row (n, Y) per blockIdx.y; threads run over X * C/4: only 32-bit index math
     const int C4 = C / 4;
     const int rowlen = W * C4;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ 
             } else {
                 const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) d[k] = bf2f((unsigned short)v[k]);
+                for (int k = 0; k < 4; ++k) d[k] = x16tof((unsigned short)v[k], f16);
             }
         };
         ld(base + ((long)y0 * w + x0) * C, p00);
@@ -136,13 +137,13 @@ __global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ 
                                                                         : taby + (long)Y * half + (c - half));
             r[0] += e.x; r[1] += e.y; r[2] += e.z; r[3] += e.w;
         }
-        T* o = out + ((n * H + Y) * (long)W + X) * C + c4 * 4;
-        if (sizeof(T) == 4) {
+        TO* o = out + ((n * H + Y) * (long)W + X) * C + c4 * 4;
+        if (sizeof(TO) == 4) {
             *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
         } else {
             bf16x4 v;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (short)f2bf(r[k]);
+            for (int k = 0; k < 4; ++k) v[k] = (short)f2x16(r[k], f16);
             *reinterpret_cast<bf16x4*>(o) = v;
         }
     }
@@ -232,7 +233,10 @@ int bilinear_ac_planes_launch(const float* in, unsigned short* out, int N, int h
 }
 
 int bilinear_ac_launch(const void* in, void* out, int dtype, int N, int h, int w, int H, int W, int C,
-                       hipStream_t st, const float* tabx, const float* taby) {
+                       hipStream_t st, const float* tabx, const float* taby, int out_dtype) {
+    if (out_dtype < 0) out_dtype = dtype;
+    SKIMI_CHECK_ARG(out_dtype == dtype || (dtype != SKIMI_F32 && out_dtype == SKIMI_F32),
+                    "bilinear resize: the output type is the input's, or fp32 from a 16-bit map");
     SKIMI_CHECK_ARG(C % 4 == 0, "bilinear resize needs C %% 4 == 0");
     SKIMI_CHECK_ARG(tabx == nullptr || (taby != nullptr && C % 8 == 0), "fused uv pos embed needs both tables, C %% 8 == 0");
     SKIMI_CHECK_ARG((long)N * H < 65536, "bilinear resize: N * H must be < 65536");
@@ -240,9 +244,12 @@ int bilinear_ac_launch(const void* in, void* out, int dtype, int N, int h, int w
     if (dtype == SKIMI_F32)
         hipLaunchKernelGGL(bilinear_ac_kernel<float>, grid, dim3(256), 0, st, (const float*)in, (float*)out, N, h, w, H, W, C,
                            tabx, taby);
+    else if (out_dtype == SKIMI_F32)
+        hipLaunchKernelGGL((bilinear_ac_kernel<unsigned short, float>), grid, dim3(256), 0, st, (const unsigned short*)in,
+                           (float*)out, N, h, w, H, W, C, tabx, taby, dtype == SKIMI_F16);
     else
         hipLaunchKernelGGL(bilinear_ac_kernel<unsigned short>, grid, dim3(256), 0, st, (const unsigned short*)in,
-                           (unsigned short*)out, N, h, w, H, W, C, tabx, taby);
+                           (unsigned short*)out, N, h, w, H, W, C, tabx, taby, dtype == SKIMI_F16);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }
@@ -253,7 +260,7 @@ int bilinear_ac_launch(const void* in, void* out, int dtype, int N, int h, int w
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void add_uv_pos_kernel(T* __restrict__ x, const float* __restrict__ tabx,
-                                                         const float* __restrict__ taby, int N, int H, int W, int C) {
+                                                         const float* __restrict__ taby, int N, int H, int W, int C, bool f16 = false) {
     const int C4 = C / 4, half = C / 2;
     const long total = (long)N * H * W * C4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -269,10 +276,10 @@ __global__ __launch_bounds__(256) void add_uv_pos_kernel(T* __restrict__ x, cons
             *reinterpret_cast<float4*>(p) = v;
         } else {
             bf16x4 v = *reinterpret_cast<bf16x4*>(p);
-            v[0] = (short)f2bf(bf2f((unsigned short)v[0]) + e.x);
-            v[1] = (short)f2bf(bf2f((unsigned short)v[1]) + e.y);
-            v[2] = (short)f2bf(bf2f((unsigned short)v[2]) + e.z);
-            v[3] = (short)f2bf(bf2f((unsigned short)v[3]) + e.w);
+            v[0] = (short)f2x16(x16tof((unsigned short)v[0], f16) + e.x, f16);
+            v[1] = (short)f2x16(x16tof((unsigned short)v[1], f16) + e.y, f16);
+            v[2] = (short)f2x16(x16tof((unsigned short)v[2], f16) + e.z, f16);
+            v[3] = (short)f2x16(x16tof((unsigned short)v[3], f16) + e.w, f16);
             *reinterpret_cast<bf16x4*>(p) = v;
         }
     }
@@ -286,7 +293,7 @@ int add_uv_pos_launch(void* x, int dtype, const float* tabx, const float* taby, 
         hipLaunchKernelGGL(add_uv_pos_kernel<float>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st, (float*)x, tabx, taby, N, H, W, C);
     else
         hipLaunchKernelGGL(add_uv_pos_kernel<unsigned short>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, st,
-                           (unsigned short*)x, tabx, taby, N, H, W, C);
+                           (unsigned short*)x, tabx, taby, N, H, W, C, dtype == SKIMI_F16);
     SKIMI_LAUNCH_CHECK();
     return SKIMI_OK;
 }

