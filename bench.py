@@ -253,7 +253,8 @@ def main():
                               else "fp32 frames resident in HBM when the timed region starts"),
                    "views": S_VIEWS, "image": IMG, "time_steps_per_call": B, "streams": NS, "parallelism": f"clip-dp{world}",
                    "aggregator_prec": ("fp16 operands in the Linears (patch embed, qkv, proj, fc1, fc2: v_mfma_f32_32x32x16_f16), bf16 attention "
-                                       "products, fp32 accumulate/residual/LayerNorm/softmax" if args.prec == "f16" else
+                                       "products, fp32 accumulate/residual/LayerNorm/softmax; fp16 is the reference's autocast format below "
+                                       "compute capability 8 (vggt/vggt/infer.py:77-82)" if args.prec == "f16" else
                                        "bf16 MFMA, fp32 accumulate/residual/LayerNorm/softmax"),
                    "head_prec": "bf16x3 (fp32-accurate)"},
         "whole_path_tflops": vggt_flops_per_step(S_VIEWS, track) * B * NS * args.steps * world / elapsed / 1e12,

@@ -63,7 +63,8 @@ extern "C" {
 #define SKIMI_PREC_FP8 2
 /* SKIMI_PREC_F16: the Linear layers of the DINOv2 / frame / global blocks and the patch embedding
  * (vggt/vggt/layers/block.py:77-98, mlp.py:34-40, attention.py:50-72, patch_embed.py:65-78) with fp16 operands on
- * v_mfma_f32_32x32x16_f16, fp32 accumulate: the same matrix rate as bf16 with three more mantissa bits.  The operand
+ * v_mfma_f32_32x32x16_f16, fp32 accumulate: the same matrix rate as bf16 with three more mantissa bits (fp16 is the
+ * reference's own autocast format on GPUs below compute capability 8, vggt/vggt/infer.py:77-82).  The operand
  * rounding of the Linears is what puts bf16 outside north_star's 1e-3 on the joints (profiles/r03_precision_ablation.md);
  * with fp16 there the joints are inside it.  LayerNorm, the attention epilogue and fc1's GELU epilogue write fp16;
  * the attention products (QK^T, PV: they average their rounding noise over all keys) keep bf16 q, k, v, P; residual
