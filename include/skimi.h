@@ -309,8 +309,10 @@ typedef struct skimi_vggt_config {
      * autocast, infer.py:78-84), SKIMI_PREC_F16 (fp16 operands: the joints stay within 1e-3 of the fp32 path),
      * SKIMI_PREC_BF16X3 (fp32-accurate) or SKIMI_PREC_FP8 */
     int32_t prec;
-    /* MFMA mode of the camera/DPT heads, which the reference runs in fp32
-     * (torch.cuda.amp.autocast(enabled=False), vggt.py:65): BF16X3 = faithful, BF16 = fast */
+    /* MFMA mode of the depth / point DPT heads, which the reference runs in fp32 (torch.cuda.amp.autocast(enabled=False),
+     * vggt.py:65): BF16X3 = faithful (the default everywhere); F16 / BF16 = 16-bit operands and activations, faster and
+     * less accurate (fp16: depth ~1e-3 worst-case relative, profiles/r03_head_precision.json).  The camera head is
+     * fp32-accurate in every mode. */
     int32_t head_prec;
 } skimi_vggt_config;
 

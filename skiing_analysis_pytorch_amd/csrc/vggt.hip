@@ -1088,8 +1088,9 @@ skimi_vggt* skimi_vggt_create(const skimi_vggt_config* cfg) {
         set_error("skimi_vggt_create: prec %d is not one of SKIMI_PREC_BF16 / BF16X3 / FP8 / F16", cfg->prec);
         return nullptr;
     }
-    if (cfg->head_prec != SKIMI_PREC_BF16 && cfg->head_prec != SKIMI_PREC_BF16X3) {
-        set_error("skimi_vggt_create: head_prec %d: the heads run in SKIMI_PREC_BF16X3 (the reference's fp32) or SKIMI_PREC_BF16", cfg->head_prec);
+    if (cfg->head_prec != SKIMI_PREC_BF16 && cfg->head_prec != SKIMI_PREC_BF16X3 && cfg->head_prec != SKIMI_PREC_F16) {
+        set_error("skimi_vggt_create: head_prec %d: the depth / point heads run in SKIMI_PREC_BF16X3 (the reference's fp32) or, as a "
+                  "faster, less accurate option, on SKIMI_PREC_F16 / SKIMI_PREC_BF16 operands", cfg->head_prec);
         return nullptr;
     }
     skimi_vggt* h = new skimi_vggt();

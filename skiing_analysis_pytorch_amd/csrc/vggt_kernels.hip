@@ -349,7 +349,7 @@ int pose_update_launch(const float* delta, float* pred_pad, float* act_out, long
 template <typename T, int NOUT>
 __global__ __launch_bounds__(256) void dpt_out_kernel(const T* __restrict__ in, const float* __restrict__ Wt,
                                                       const float* __restrict__ b, float* __restrict__ pts,
-                                                      float* __restrict__ conf, long npix, int mode) {
+                                                      float* __restrict__ conf, long npix, int mode, bool f16 = false) {
     __shared__ float ws[NOUT * 32 + NOUT];
     for (int i = threadIdx.x; i < NOUT * 32 + NOUT; i += 256) ws[i] = i < NOUT * 32 ? Wt[i] : b[i - NOUT * 32];
     __syncthreads();
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void dpt_out_kernel(const T* __restrict__ in, 
             for (int k = 0; k < 4; ++k) {
                 const bf16x8 t = *reinterpret_cast<const bf16x8*>((const unsigned short*)in + px * 32 + 8 * k);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[8 * k + j] = bf2f((unsigned short)t[j]);
+                for (int j = 0; j < 8; ++j) v[8 * k + j] = x16tof((unsigned short)t[j], f16);
             }
         }
         float o[NOUT];
@@ -392,7 +392,7 @@ int dpt_out_launch(const void* in, int dtype, const float* W, const float* b, in
                    long npix, int mode, hipStream_t st) {
     SKIMI_CHECK_ARG(n_out == 2 || n_out == 4, "dpt output stage supports 2 or 4 channels (got %d)", n_out);
     dim3 g(grid_for(npix, 256, 16384)), blk(256);
-#define GO(T, N) hipLaunchKernelGGL((dpt_out_kernel<T, N>), g, blk, 0, st, (const T*)in, W, b, pts, conf, npix, mode)
+#define GO(T, N) hipLaunchKernelGGL((dpt_out_kernel<T, N>), g, blk, 0, st, (const T*)in, W, b, pts, conf, npix, mode, dtype == SKIMI_F16)
     if (dtype == SKIMI_F32) { if (n_out == 2) GO(float, 2); else GO(float, 4); }
     else { if (n_out == 2) GO(unsigned short, 2); else GO(unsigned short, 4); }
 #undef GO

@@ -179,6 +179,28 @@ def test_f16_mode_meets_the_joints_bar_at_bench_shape(bench_shape):
     assert pe < pe16 / 3, (pe, pe16)
 
 
+def test_f16_heads_option_at_bench_shape(bench_shape):
+    """head_prec = PREC_F16: the depth / point DPT heads on fp16 operands and activations (one MFMA per product instead of
+    three) -- an OPTION, not what bench.py's headline runs: the reference computes these heads in fp32 (vggt.py:65), and
+    fp16 convolutions leave the dense maps at ~1e-3 worst-case relative error (emulated: profiles/r03_head_precision.json;
+    measured here).  The camera head stays fp32-accurate, so pose_enc and the joints are those of the default heads."""
+    s = bench_shape
+    m = vggt.VGGT(config=s["cfg"], prec=PREC_F16, head_prec=PREC_F16)
+    m.load_state_dict(s["sd"])
+    out = m(s["images"].cuda(), want={"camera", "depth", "point"})
+    torch.cuda.synchronize()
+    ref = s["ref"]
+    pe = (out["pose_enc"].cpu() - ref["pose_enc"]).abs().max().item()
+    msg = [f"f16 heads: pose_enc max abs err {pe:.3e}"]
+    for k in ("depth", "depth_conf", "world_points", "world_points_conf"):
+        assert out[k].shape == ref[k].shape and torch.isfinite(out[k]).all(), k
+        rel = (out[k].cpu() - ref[k]).abs() / (ref[k].abs() + 1.0)
+        msg.append(f"{k} rel err median {rel.median().item():.2e} max {rel.max().item():.2e}")
+        assert rel.median().item() < 1e-3 and rel.max().item() < 1e-2, k
+    print("; ".join(msg))
+    assert pe < 2e-3 and _ring_mpjpe(out, s) < 1e-3
+
+
 def test_fp8_mode_forward_at_bench_shape(bench_shape):
     """BASELINE config 5 (VGGT with e4m3 weights): SKIMI_PREC_FP8 -- MXFP8 qkv / fc1 / fc2 in the 72 blocks -- at VGGT-1B
     size against the fp32 oracle.  The reference has no fp8 path (parity unpinned: the quantiser is pinned against the
