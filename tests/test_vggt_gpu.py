@@ -141,6 +141,19 @@ def test_vggt_fullsize_fp32_mode_vs_oracle(H, W, head, monkeypatch):
     assert rel.max().item() < 1e-3, rel.max().item()
     relc = (out[ckey].cpu() - ref[ckey]).abs() / (ref[ckey].abs() + 1.0)
     assert relc.max().item() < 1e-3
+    # The fp16 mode on the same frames (S = 2: M = 2748 / 1564 token rows -- the small-launch side of the fp16 kernels:
+    # generic GEMM for the narrow Linears, 256-row loops for the wide ones, ragged 294 x 518 tiles): fp16-level agreement
+    # with the fp32 oracle on the camera parameters and the dense map
+    from skiing_analysis_pytorch_amd._lib import PREC_F16
+
+    m16 = vggt.VGGT(config=cfg, prec=PREC_F16, head_prec=PREC_BF16X3)
+    m16.load_state_dict(cpu_sd)
+    o16 = m16(img.cuda(), want={"camera", head})
+    pe16 = _maxerr(o16["pose_enc"].cpu(), ref["pose_enc"])
+    rel16 = (o16[key].cpu() - ref[key]).abs() / (ref[key].abs() + 1.0)
+    print(f"fp16 mode at {H}x{W}, S = 2: pose_enc max abs err {pe16:.2e}, {key} rel err median {rel16.median().item():.2e} max {rel16.max().item():.2e}")
+    assert pe16 < 3e-3 and rel16.median().item() < 1e-3 and rel16.max().item() < 2e-2
+    del m16
     # The same forward with the DPT convs forced onto the LDS-DMA bf16x3 kernels (picked on their own only
     # for most of a chip's worth of 256-row tiles (>= 160), i.e. the 32-frame bench batch): activations handed from conv to conv
     # as bf16x3 records, upsample -> records, two-residual epilogue.
