@@ -204,3 +204,27 @@ def test_track_head_at_16_bit_precision(golden_dir, prec):
     assert np.abs(out["vis"].cpu().numpy() - g["vis"]).max() < 0.1 and np.abs(out["conf"].cpu().numpy() - g["conf"]).max() < 0.1
     assert torch.allclose(out["track"][0, 0].cpu(), torch.from_numpy(g["query_points"]), atol=1e-4)
     assert torch.equal(out["track"], m(images, query_points=q, want={"track"})["track"]) or True   # (atomics: not bit-stable)
+
+
+def test_attention_f16_output_on_the_32_query_kernel():
+    """SKIMI_ATTN_Q64=0 (the first, 32-query attention kernel; read once per process, hence a child process) also writes
+    fp16 result rows when asked to"""
+    import os, subprocess, sys
+    code = (
+        "import torch, torch.nn.functional as F\n"
+        "from skiing_analysis_pytorch_amd import ops\n"
+        "worst = 0.0\n"
+        "for batch, seq, heads in [(2, 77, 3), (1, 1374, 2), (2, 257, 2)]:\n"
+        "    g = torch.Generator().manual_seed(61)\n"
+        "    qkv = torch.randn(batch * seq, 3 * heads * 64, generator=g).to(torch.bfloat16).cuda()\n"
+        "    out = ops.attention(qkv, batch, seq, heads, 64, out_dtype=torch.float16)\n"
+        "    assert out.dtype == torch.float16\n"
+        "    x = qkv.float().cpu().reshape(batch, seq, 3, heads, 64).permute(2, 0, 3, 1, 4)\n"
+        "    ref = F.scaled_dot_product_attention(x[0], x[1], x[2]).transpose(1, 2).reshape(batch * seq, -1)\n"
+        "    worst = max(worst, (out.float().cpu() - ref).abs().max().item())\n"
+        "print('WORST', worst)\n")
+    env = dict(os.environ, SKIMI_ATTN_Q64="0")
+    root = str(__import__("pathlib").Path(__file__).resolve().parent.parent)
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert float(r.stdout.strip().split("WORST")[-1]) < 2e-2
