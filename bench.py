@@ -381,6 +381,10 @@ def main():
         else:
             line["value_within_bar"], line["mode_within_bar"] = None, None
     if rank == 0:
+        if "within_bar" not in line:   # no CPU-oracle leg in this run (N > 1 or --no-cpu-baseline): the bar is judged by the N = 1 run
+            line["within_bar"] = None
+            line["within_bar_note"] = ("not measured in this run: the joints-vs-CPU-oracle leg runs on rank 0 at N = 1 only; the same mode measured "
+                                       "4.7e-4 ring-rig MPJPE there (profiles/r03_bench_line.json)")
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
