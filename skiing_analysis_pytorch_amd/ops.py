@@ -82,6 +82,7 @@ def gemm(a, w, *, prec=PREC_BF16X3, bias=None, gamma=None, resid=None, act=ACT_N
     d.bias, d.gamma, d.resid = ptr(bias), ptr(gamma), ptr(resid)
     if resid is not None:
         d.ldr = resid.stride(-2)
+        d.resid_dtype = _dt(resid)
     if resid_map is not None:
         d.resid_rows_per_batch, d.resid_batch_stride, d.resid_row_off = resid_map
     d.act = act
