@@ -252,3 +252,61 @@ def test_config4_chain_clip_to_smoothed_joints_matches_oracle_chain(tiny):
     # two batches in flight (two host threads / HIP streams) give the same clip
     out2 = infer.process_multi_view_clip(m, frames.cuda(), kps.cuda(), steps_per_call=1, smooth=True, streams=2)
     assert np.abs(out2["joints3d_smoothed"].numpy() - out["joints3d_smoothed"].numpy()).max() / scale < 1e-4
+
+
+def _clip_inputs(T=5, S=3, H=140, Wd=140):
+    frames = torch.stack([W.make_images(S, H, Wd, seed=60 + t) for t in range(T)])
+    g = torch.Generator().manual_seed(9)
+    kps = torch.rand((T, S, 17, 2), generator=g) * (Wd - 40) + 20
+    return frames, kps
+
+
+def _rank_worker(rank, world, port, golden_path, q):
+    """one rank of the two-rank clip: both ranks share cuda:0 (a one-GPU box), the collective runs over gloo"""
+    import os
+
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = np.load(golden_path)
+        cfg = W.VGGTConfig(**json.loads(str(g["cfg_json"])))
+        m = vggt.VGGT(config=cfg, prec=PREC_BF16X3, head_prec=PREC_BF16X3)
+        m.load_state_dict(W.make_vggt_state_dict(cfg, seed=0))
+        frames, kps = _clip_inputs()
+        out = infer.process_multi_view_clip(m, frames.cuda(), kps.cuda(), steps_per_call=2, smooth=True)
+        q.put((rank, out["joints3d"].cpu().numpy(), out["joints3d_smoothed"].numpy(), out["extrinsic"].cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_clip_sharded_over_two_ranks_equals_one_rank(tiny, golden_dir):
+    """BASELINE config 4 across ranks, with the real model: two processes (gloo; both on this box's one GPU) shard the 5 time
+    steps of a clip 3 + 2 (the second rank's block is padded by repeating the last step and cut after the gather), exchange
+    joints + cameras in the one packed all-gather, smooth -- and every rank holds exactly what one process computes alone (the
+    fp32-accurate mode is run-to-run deterministic, so bit for bit)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    cfg, sd, m = tiny
+    frames, kps = _clip_inputs()
+    one = infer.process_multi_view_clip(m, frames.cuda(), kps.cuda(), steps_per_call=2, smooth=True)
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, str(golden_dir / "vggt_tiny_conv.npz"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, j, js, E in res:
+        assert j.shape == (5, 17, 3) and js.shape == (5, 17, 3) and E.shape == (5, 3, 3, 4)
+        assert np.array_equal(j, one["joints3d"].cpu().numpy()), rank
+        assert np.array_equal(js, one["joints3d_smoothed"].numpy()), rank
+        assert np.array_equal(E, one["extrinsic"].cpu().numpy()), rank
