@@ -312,7 +312,7 @@ def main():
         active["model"] = model
         other_model = mo
     if rank == 0 and world == 1 and not args.no_fp8:
-        # BASELINE config 5: the same step with the qkv / fc1 / fc2 Linears of every block on the MXFP8 MFMA
+        # BASELINE config 5: the same step with the four Linears (qkv / proj / fc1 / fc2) of every block on the MXFP8 MFMA
         # (SKIMI_PREC_FP8); not part of `value`.  Same inputs, same step code, its own timed region.
         from skiing_analysis_pytorch_amd._lib import PREC_FP8
         m8 = vggt.VGGT(config=cfg, prec=PREC_FP8, head_prec=PREC_BF16X3)
@@ -330,10 +330,10 @@ def main():
         dt8 = (time.perf_counter() - t8) / n8
         assert torch.isfinite(out8["pose_enc"]).all()
         line["fp8"] = {"value": B * NS / dt8, "unit": "frames/s", "ms_per_step": dt8 * 1e3, "steps": n8,
-                       "mode": "SKIMI_PREC_FP8: MXFP8 (e4m3 + E8M0 per 32 K) qkv / fc1 / fc2 of the 72 blocks on "
+                       "mode": "SKIMI_PREC_FP8: MXFP8 (e4m3 + E8M0 per 32 K) qkv / proj / fc1 / fc2 of the 72 blocks on "
                                "v_mfma_scale_f32_32x32x64_f8f6f4, activations quantised inside their producers (LayerNorm -> "
-                               "MXFP8, fc1's GELU epilogue -> MXFP8); attention, proj, residual stream as the bf16 mode; "
-                               "heads bf16x3",
+                               "MXFP8, the attention kernel's output rows -> MXFP8, fc1's GELU epilogue -> MXFP8); attention "
+                               "products and residual stream as the bf16 mode; heads bf16x3",
                        "pose_enc_max_abs_diff_vs_timed_mode": (out8["pose_enc"] - out["pose_enc"]).abs().max().item()}
         active["model"] = model
         fp8_model = m8

@@ -55,11 +55,12 @@ extern "C" {
  *                       parity bar against the fp32 CPU reference */
 #define SKIMI_PREC_BF16 0
 #define SKIMI_PREC_BF16X3 1
-/* SKIMI_PREC_FP8 (skimi_vggt_config.prec only; BASELINE config 5): as SKIMI_PREC_BF16, but the qkv / fc1 / fc2
- * Linear layers of every DINOv2 / frame / global block (vggt/vggt/layers/block.py:77-98, mlp.py:34-40,
+/* SKIMI_PREC_FP8 (skimi_vggt_config.prec only; BASELINE config 5): as SKIMI_PREC_BF16, but the four Linear layers
+ * (qkv, proj, fc1, fc2) of every DINOv2 / frame / global block (vggt/vggt/layers/block.py:77-98, mlp.py:34-40,
  * attention.py:50-72) run on the MXFP8 MFMA (skimi_gemm_fp8): weights quantised once at finalize, activations by
- * their producers (skimi_layernorm_mx; fc1's epilogue with out_dtype SKIMI_FP8MX; skimi_quant_mx where the shape
- * rules those out); attention, proj, the fp32 residual stream and the heads are unchanged. */
+ * their producers (skimi_layernorm_mx; the attention kernel's output rows, skimi_attention_out with SKIMI_FP8MX;
+ * fc1's epilogue with out_dtype SKIMI_FP8MX; skimi_quant_mx where the shape rules those out); the attention
+ * products (bf16), the fp32 residual stream and the heads are unchanged. */
 #define SKIMI_PREC_FP8 2
 /* SKIMI_PREC_F16: the Linear layers of the DINOv2 / frame / global blocks and the patch embedding
  * (vggt/vggt/layers/block.py:77-98, mlp.py:34-40, attention.py:50-72, patch_embed.py:65-78) with fp16 operands on
@@ -260,7 +261,10 @@ int skimi_attention(const void* qkv, void* out, int32_t dtype, int32_t batch, in
                     int32_t heads, int32_t head_dim, void* stream);
 /* The same with the output type named: out_dtype == dtype, or SKIMI_F16 with dtype SKIMI_BF16 -- the form
  * SKIMI_PREC_F16 runs (bf16 q / k / v and probabilities, the result rows rounded once to fp16: the operand of
- * the proj Linear, attention.py:62-64). */
+ * the proj Linear, attention.py:62-64) -- or SKIMI_FP8MX with dtype SKIMI_BF16, head_dim 64 and an even number of
+ * heads: the form SKIMI_PREC_FP8 runs, the result rows as skimi_gemm_fp8's A operand, quantised from the fp32
+ * quotient: `out` = e4m3 payload [batch*seq][Kp] followed by the E8M0 scales [batch*seq][Kp/32], Kp =
+ * heads*head_dim rounded up to 128 (pad columns are not written). */
 int skimi_attention_out(const void* qkv, void* out, int32_t dtype, int32_t out_dtype, int32_t batch, int32_t seq,
                         int32_t heads, int32_t head_dim, void* stream);
 

@@ -15,7 +15,7 @@ F32, BF16 = 0, 1
 F16 = 4          # IEEE binary16: operands / activations of PREC_F16
 BF16X3_REC = 2   # skimi_gemm_desc.a_dtype: A already split into bf16x3 records
 FP8MX = 3        # skimi_gemm_fp8 out_dtype: the result as MXFP8 payload + scales
-PREC_BF16, PREC_BF16X3, PREC_FP8 = 0, 1, 2   # PREC_FP8: VGGT aggregator only (MXFP8 qkv / fc1 / fc2)
+PREC_BF16, PREC_BF16X3, PREC_FP8 = 0, 1, 2   # PREC_FP8: VGGT aggregator only (MXFP8 qkv / proj / fc1 / fc2)
 PREC_F16 = 3     # fp16 operands on the f16 MFMA (Linears of the aggregator blocks + patch embed; skimi_gemm with fp16 / fp32 operands)
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
 

@@ -197,8 +197,15 @@ int skimi_attention(const void* qkv, void* out, int32_t dtype, int32_t batch, in
 
 int skimi_attention_out(const void* qkv, void* out, int32_t dtype, int32_t out_dtype, int32_t batch, int32_t seq,
                         int32_t heads, int32_t head_dim, void* stream) {
+    if (out_dtype == SKIMI_FP8MX) {   // payload [tokens][Kp], then the scales [tokens][Kp / 32], Kp = heads * head_dim up to 128
+        SKIMI_CHECK_ARG(out && batch > 0 && seq > 0 && attention_mx_output_ok(dtype, heads, head_dim),
+                        "skimi_attention_out: MXFP8 rows need bf16 q / k / v, head_dim 64 and an even number of heads");
+        const size_t Kp = align_up((size_t)heads * head_dim, 128);
+        return attention_launch(qkv, nullptr, dtype, batch, seq, heads, head_dim, (hipStream_t)stream, 0, nullptr, 0, nullptr, 0,
+                                out, (char*)out + (size_t)batch * seq * Kp);
+    }
     SKIMI_CHECK_ARG(out_dtype == dtype || (dtype == SKIMI_BF16 && out_dtype == SKIMI_F16),
-                    "skimi_attention_out: out_dtype is dtype, or SKIMI_F16 for bf16 q / k / v (got %d -> %d)", dtype, out_dtype);
+                    "skimi_attention_out: out_dtype is dtype, SKIMI_F16 or SKIMI_FP8MX for bf16 q / k / v (got %d -> %d)", dtype, out_dtype);
     return attention_launch(qkv, out, dtype, batch, seq, heads, head_dim, (hipStream_t)stream, 0, nullptr, 0, nullptr,
                             out_dtype == SKIMI_F16 && dtype == SKIMI_BF16);
 }

@@ -221,8 +221,21 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const AttnArgs a, int
     }
 }
 
+static int q64_enabled() {   // SKIMI_ATTN_Q64: 1 (default) the 64-query-per-wave kernel; 0 this file's 32-query kernel
+    static const int q64 = getenv("SKIMI_ATTN_Q64") ? atoi(getenv("SKIMI_ATTN_Q64")) : 1;
+    return q64;
+}
+
+// SKIMI_ATTN_MX=0: SKIMI_PREC_FP8 quantises the bf16 output rows in a separate pass instead (A/B timing, tests)
+bool attention_mx_output_ok(int dtype, int heads, int head_dim) {
+    static const bool dyn = getenv("SKIMI_ENV_DYNAMIC") && atoi(getenv("SKIMI_ENV_DYNAMIC"));
+    static int use_mx = -1;
+    if (use_mx < 0 || dyn) use_mx = getenv("SKIMI_ATTN_MX") ? atoi(getenv("SKIMI_ATTN_MX")) : 1;
+    return use_mx && dtype == SKIMI_BF16 && head_dim == 64 && heads % 2 == 0 && q64_enabled() != 0;
+}
+
 int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
-    SKIMI_CHECK_ARG(a.q && a.k && a.v && a.out, "skimi_attention: null buffer");
+    SKIMI_CHECK_ARG(a.q && a.k && a.v && (a.out || a.out_mx), "skimi_attention: null buffer");
     SKIMI_CHECK_ARG(a.batch > 0 && a.heads > 0 && a.seq_q > 0 && a.seq_k > 0, "skimi_attention: empty shape");
     SKIMI_CHECK_ARG(a.head_dim == 64, "skimi_attention: the bf16 MFMA kernel is head_dim 64 only (got %d)", a.head_dim);
     SKIMI_CHECK_ARG(a.q_row % 8 == 0 && a.k_row % 8 == 0 && a.v_row % 8 == 0 && a.o_row % 4 == 0 &&
@@ -240,8 +253,8 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
 #else
     const int dbg = 0;
 #endif
-    // SKIMI_ATTN_Q64: 1 (default) the 64-query-per-wave kernel; 0 this file's 32-query kernel
-    static const int q64 = getenv("SKIMI_ATTN_Q64") ? atoi(getenv("SKIMI_ATTN_Q64")) : 1;
+    const int q64 = q64_enabled();
+    SKIMI_CHECK_ARG(!a.out_mx || q64 != 0, "skimi_attention: MXFP8 output rows are written by the 64-query kernel only");
     if (q64 != 0) {
         attention_q64_dispatch(a, st);
     } else if (a.q_prescaled) {   // this file's kernel multiplies by scale * log2(e): make that product 1
@@ -268,8 +281,11 @@ int attention_bf16_launch(const AttnArgs& a, hipStream_t st) {
 }
 
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
-                     hipStream_t st, int q_prescaled, void* x3_scratch, size_t x3_scratch_bytes, int* out_records, int out_f16) {
-    SKIMI_CHECK_ARG(qkv && out, "skimi_attention: null buffer");
+                     hipStream_t st, int q_prescaled, void* x3_scratch, size_t x3_scratch_bytes, int* out_records, int out_f16,
+                     void* out_mx, void* out_mx_scales) {
+    SKIMI_CHECK_ARG(qkv && (out || out_mx), "skimi_attention: null buffer");
+    SKIMI_CHECK_ARG(!out_mx || (out_mx_scales && attention_mx_output_ok(dtype, heads, head_dim)),
+                    "skimi_attention: MXFP8 output needs the 64-query bf16 kernel (head_dim 64, heads even) and a scale buffer");
     const bool want_rec = out_records != nullptr && *out_records != 0;
     if (out_records) *out_records = 0;
     AttnArgs a;
@@ -291,6 +307,12 @@ int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, 
     a.scale = 1.0f / sqrtf((float)head_dim);
     a.q_prescaled = dtype == SKIMI_F32 ? 0 : q_prescaled;
     a.out_f16 = dtype == SKIMI_F32 ? 0 : out_f16;
+    if (out_mx) {   // [token][align128(C)] payload + [token][align128(C) / 32] scales: gemm_fp8_launch's A operand
+        a.out_mx = out_mx;
+        a.out_mx_scales = out_mx_scales;
+        a.mx_row = (long)align_up((size_t)C, 128);
+        a.mx_srow = a.mx_row / 32;
+    }
     if (dtype == SKIMI_F32) {
         // fp32-accurate mode: the bf16x3 kernel when the caller lends scratch for the hi / lo planes (SKIMI_ATTN_X3=0: the
         // exact-fp32 MFMA kernel, A/B timing and a cross-check in the tests)

@@ -290,6 +290,34 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
     for (int qi = 0; qi < 2; ++qi) {
         const float inv = 1.f / xhalf_sum(lsum[qi]);
         const int q = q0 + qi * 32 + l31;
+        if (a.out_mx) {
+            // MXFP8 rows (proj's A operand under SKIMI_PREC_FP8): a 32-channel block = one dt half of this head, 16 of its
+            // values in this lane and 16 in lane ^ 32 -> one permlane swap for the block maximum, quantised from the fp32
+            // quotient (one rounding, like LayerNorm's MX output)
+            const long tok = (long)b * a.seq_q + q;
+            unsigned char* pq = (unsigned char*)a.out_mx + tok * a.mx_row + head * 64;
+            unsigned char* ps = (unsigned char*)a.out_mx_scales + tok * a.mx_srow + head * 2;
+            unsigned sb2 = 0;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                float amax = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) amax = __builtin_fmaxf(amax, __builtin_fabsf(o[qi][dt][j] * inv));
+                amax = xhalf_max(amax);
+                const unsigned sb = mx_scale_byte(amax);
+                const float si = mx_inv_scale(sb);
+                sb2 |= sb << (8 * dt);
+                if (q < a.seq_q) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<int*>(pq + dt * 32 + 8 * g + 4 * lh) =
+                            mx_pack4(o[qi][dt][4 * g] * inv, o[qi][dt][4 * g + 1] * inv, o[qi][dt][4 * g + 2] * inv,
+                                     o[qi][dt][4 * g + 3] * inv, si);
+                }
+            }
+            if (q < a.seq_q && lh == 0) *reinterpret_cast<unsigned short*>(ps) = (unsigned short)sb2;
+            continue;
+        }
         if (q < a.seq_q) {
             unsigned short* op = O + (long)q * a.o_row;
 #pragma unroll

@@ -36,7 +36,14 @@ struct AttnArgs {
     long q_batch2 = 0, k_batch2 = 0, v_batch2 = 0, o_batch2 = 0;
     int q_prescaled = 0;   // bf16 kernels: q already carries scale * log2(e) (qknorm_rope_launch's q_scale)
     int out_f16 = 0;       // bf16 kernels: the output rows are written as fp16 (proj's operand under SKIMI_PREC_F16)
+    // 64-query kernel only (attention_mx_output_ok): the output rows as MXFP8 instead of `out` -- payload [token][mx_row]
+    // e4m3 bytes, one E8M0 byte per 32 channels in [token][mx_srow] (proj's A operand under SKIMI_PREC_FP8)
+    void* out_mx = nullptr;
+    void* out_mx_scales = nullptr;
+    long mx_row = 0, mx_srow = 0;
 };
+// the bf16 attention launch can write its output as MXFP8 (one head = two 32-channel blocks, each inside one lane pair)
+bool attention_mx_output_ok(int dtype, int heads, int head_dim);
 int attention_f32_launch(const AttnArgs& a, hipStream_t st);
 int attention_bf16_launch(const AttnArgs& a, hipStream_t st);
 // preprocess.hip: Pillow-exact separable uint8 resample pass, uint8 HWC -> fp32 CHW / 255 with crop / pad
@@ -53,7 +60,8 @@ void attention_q64_dispatch(const AttnArgs& a, hipStream_t st);    // attention_
 int attention_launch(const void* qkv, void* out, int dtype, int batch, int seq, int heads, int head_dim,
                      hipStream_t st, int q_prescaled = 0, void* x3_scratch = nullptr, size_t x3_scratch_bytes = 0,
                      int* out_records = nullptr,    // in: bf16x3 records wanted in `out` (fp32 mode); out: whether they were written
-                     int out_f16 = 0);              // bf16 q / k / v, fp16 output rows (SKIMI_PREC_F16)
+                     int out_f16 = 0,               // bf16 q / k / v, fp16 output rows (SKIMI_PREC_F16)
+                     void* out_mx = nullptr, void* out_mx_scales = nullptr);   // attention_mx_output_ok(): MXFP8 rows instead of `out`
 // attention_x3.hip: fp32-accurate attention (head_dim 64) on the bf16 matrix pipe, operands split hi + lo; needs
 // scratch for the hi / lo planes of the packed qkv buffer (attention_launch uses it for fp32 inputs when given)
 size_t attention_x3_scratch_bytes(long tokens, long row_elems);

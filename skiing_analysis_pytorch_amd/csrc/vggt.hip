@@ -305,6 +305,8 @@ struct Packer {
         }
         if (fp8) {
             add_fp8(b.qkv, p + ".attn.qkv", 3 * C, C);
+            // SKIMI_FP8_PROJ=0 (read when the weights are packed): proj stays on the bf16 kernel, as in round 2 (A/B timing)
+            if (!(getenv("SKIMI_FP8_PROJ") && atoi(getenv("SKIMI_FP8_PROJ")) == 0)) add_fp8(b.proj, p + ".attn.proj", C, C);
             add_fp8(b.fc1, p + ".mlp.fc1", hidden, C);
             add_fp8(b.fc2, p + ".mlp.fc2", C, hidden);
         }
@@ -443,11 +445,13 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
     // converts its output to fp16 for proj
     const int qdt = adt == SKIMI_F16 ? SKIMI_BF16 : adt;
     const int hidden = w.fc1.N;
-    const bool fp8 = w.qkv.wq != nullptr && b.q8 != nullptr;   // SKIMI_PREC_FP8: qkv, fc1, fc2 on the MXFP8 MFMA
-    // the quantisation rides in the producers where the shapes allow: LayerNorm writes MXFP8 directly (C % 256 == 0), and
-    // fc1's GELU epilogue writes the hidden activation as MXFP8 (large launches on the single-stream loop)
+    const bool fp8 = w.qkv.wq != nullptr && b.q8 != nullptr;   // SKIMI_PREC_FP8: qkv, proj, fc1, fc2 on the MXFP8 MFMA
+    // the quantisation rides in the producers where the shapes allow: LayerNorm writes MXFP8 directly (C % 256 == 0),
+    // the attention kernel writes its output rows as MXFP8 (64-wide heads), and fc1's GELU epilogue writes the hidden
+    // activation as MXFP8 (large launches on the single-stream loop)
     const bool ln_mx = fp8 && C % 256 == 0;
     const bool hid_mx = fp8 && gemm_fp8_mx_output_ok(M, hidden);
+    const bool ao_mx = fp8 && w.proj.wq != nullptr && attention_mx_output_ok(qdt, heads, C / heads);
     // fp32-accurate mode: a Linear whose launch takes the LDS-DMA bf16x3 kernel reads its A operand as [hi 32 | lo 32]
     // records; where the producer can write them (LayerNorm, fc1's GELU epilogue) the fp32 copy and the split pass go
     auto as_records = [&](skimi_gemm_desc d, void* rec, size_t rec_bytes) {
@@ -495,9 +499,17 @@ void run_block(Ctx& c, const BlockW& w, float* x, int batch, int seq, int C, int
     }
     if (!c.rc && !c.dry())
         c.rc = attention_launch(b.qkv, b.ao, qdt, batch, seq, heads, C / heads, c.st, q_scaled, adt == SKIMI_F32 ? b.hid : nullptr,
-                                adt == SKIMI_F32 ? (size_t)M * hidden * 4 : 0, &ao_rec, adt == SKIMI_F16);
+                                adt == SKIMI_F32 ? (size_t)M * hidden * 4 : 0, &ao_rec, adt == SKIMI_F16,
+                                ao_mx ? b.q8 : nullptr, ao_mx ? b.q8s : nullptr);
     if (ao_rec && !c.dry()) d_proj = as_records(d_proj, b.ao, (size_t)M * C * 4);
-    c.gemm(d_proj);
+    if (fp8 && w.proj.wq) {
+        if (!ao_mx && !c.rc && !c.dry()) c.rc = quant_mx_launch(b.ao, SKIMI_BF16, C, M, C, b.q8, b.q8s, c.st);
+        if (!c.rc && !c.dry())
+            c.rc = gemm_fp8_launch(b.q8, b.q8s, w.proj.wq, w.proj.wq_scales, M, C, C, w.proj.b, SKIMI_ACT_NONE, w.ls1, x, C, x,
+                                   SKIMI_F32, C, c.st);
+    } else {
+        c.gemm(d_proj);
+    }
     auto d_fc1 = c.desc(w.fc1, b.xn, adt, C, M, b.hid, adt, hidden);
     d_fc1.act = SKIMI_ACT_GELU;
     auto d_fc2 = c.desc(w.fc2, b.hid, adt, hidden, M, x, SKIMI_F32, C);

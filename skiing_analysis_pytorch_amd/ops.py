@@ -130,8 +130,16 @@ def qknorm_rope_(qkv, heads, qn_w=None, qn_b=None, kn_w=None, kn_b=None, eps=1e-
 
 def attention(qkv, batch, seq, heads, head_dim, out_dtype=None):
     """qkv: [batch*seq, 3*heads*head_dim] -> [batch*seq, heads*head_dim] (same dtype; out_dtype=torch.float16 with
-    bf16 qkv: the result rows as fp16, PREC_F16's proj operand)"""
+    bf16 qkv: the result rows as fp16, PREC_F16's proj operand; out_dtype="fp8mx" with bf16 qkv, head_dim 64: the result
+    rows as MXFP8 -> (payload uint8 [rows, Kp], scales uint8 [rows, Kp/32]), PREC_FP8's proj operand)"""
     _require_cuda(qkv)
+    if isinstance(out_dtype, str):
+        assert out_dtype == "fp8mx", out_dtype
+        rows, Kp = batch * seq, (heads * head_dim + 127) // 128 * 128
+        buf = torch.zeros(rows * (Kp + Kp // 32), dtype=torch.uint8, device=qkv.device)
+        check(lib().skimi_attention_out(ptr(qkv), ptr(buf), _dt(qkv), _lib.FP8MX, batch, seq, heads, head_dim,
+                                        _lib.current_stream()), "skimi_attention_out")
+        return buf[:rows * Kp].view(rows, Kp), buf[rows * Kp:].view(rows, Kp // 32)
     out = torch.empty((batch * seq, heads * head_dim), dtype=out_dtype or qkv.dtype, device=qkv.device)
     if out_dtype is None or out_dtype == qkv.dtype:
         check(lib().skimi_attention(ptr(qkv), ptr(out), _dt(qkv), batch, seq, heads, head_dim, _lib.current_stream()),

@@ -47,7 +47,7 @@ class VGGT:
 
     prec: MFMA mode of the DINOv2 + aggregator blocks (PREC_BF16 = the reference's autocast mode; PREC_F16 = fp16
     operands in the Linears at the same matrix rate, the cheapest mode whose 3D joints stay within 1e-3 of the fp32
-    CPU path; PREC_BF16X3 = fp32-accurate; PREC_FP8 = MXFP8 qkv / fc1 / fc2).  head_prec: mode of the camera/DPT heads, which the reference
+    CPU path; PREC_BF16X3 = fp32-accurate; PREC_FP8 = MXFP8 qkv / proj / fc1 / fc2).  head_prec: mode of the camera/DPT heads, which the reference
     runs in fp32 (vggt.py:65)."""
 
     def __init__(self, img_size=518, patch_size=14, embed_dim=1024, enable_camera=True, enable_point=True,

@@ -127,8 +127,39 @@ def test_gemm_fp8_mx_output(M, N, K):
     assert np.abs(o_f.cpu().numpy() - o_r).max() < 1e-4 * np.abs(o_r).max()
 
 
+@pytest.mark.parametrize("batch,seq,heads", [(2, 300, 2), (1, 1374, 4), (3, 64, 6)])
+def test_attention_mx_output(batch, seq, heads):
+    """The attention kernel's MXFP8 output rows (skimi_attention_out with SKIMI_FP8MX: proj's operand under PREC_FP8,
+    attention.py:60-64) are the quantisation of its fp32 quotient: against the float64 attention of the same bf16 q / k / v
+    within the e4m3 step, and against the oracle quantiser applied to the kernel's own bf16 rows (those differ by the
+    bf16 rounding in front of the quantiser only: same scale byte except at a power-of-two edge, payload within one code)."""
+    hd, C = 64, heads * 64
+    g = torch.Generator().manual_seed(seq + heads)
+    qkv = (torch.randn(batch * seq, 3 * C, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    q8, s8 = ops.attention(qkv, batch, seq, heads, hd, out_dtype="fp8mx")
+    o16 = ops.attention(qkv, batch, seq, heads, hd)
+    assert q8.shape == (batch * seq, C) and s8.shape == (batch * seq, C // 32)
+    got = mx.mx_dequantize(q8.cpu().numpy(), s8.cpu().numpy())
+    x = qkv.double().view(batch, seq, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    p = torch.softmax(x[0] @ x[1].transpose(-1, -2) / 8.0, dim=-1)
+    ref = (p @ x[2]).permute(0, 2, 1, 3).reshape(batch * seq, C).cpu().numpy()
+    scale = np.exp2(s8.cpu().numpy().astype(np.float64) - 127.0).repeat(32, axis=1)
+    # e4m3: 3 mantissa bits (half a step = 2^-4 relative), subnormal step 2^-9 of the block scale; the kernel's own bf16
+    # probabilities and output rounding stay within 1.5e-2 of the row maximum (test_ops_gpu.py bounds the bf16 kernel at 2e-2)
+    tol = 2.0 ** -4 * np.abs(ref) + scale * 2.0 ** -10 + 1.5e-2 * np.abs(ref).max(axis=1, keepdims=True)
+    assert (np.abs(got - ref) <= tol).all(), float((np.abs(got - ref) - tol).max())
+    qr, sr = mx.mx_quantize(o16.float().cpu().numpy())
+    same_scale = (sr == s8.cpu().numpy())
+    assert same_scale.mean() > 0.98 and np.abs(sr.astype(np.int32) - s8.cpu().numpy().astype(np.int32)).max() <= 1
+    want = mx.mx_dequantize(qr, sr)
+    blk = same_scale.repeat(32, axis=1)
+    step = 2.0 ** -3 * np.maximum(np.abs(got), np.abs(want)) + scale * 2.0 ** -9
+    assert (np.abs(got - want)[blk] <= step[blk]).all()
+    assert (q8.cpu().numpy() == qr)[blk].mean() > 0.9
+
+
 def test_vggt_fp8_mode_against_reference(golden_dir):
-    """PREC_FP8 (MXFP8 qkv / fc1 / fc2 in every block, everything else as the bf16 mode) on the tiny golden: finite,
+    """PREC_FP8 (MXFP8 qkv / proj / fc1 / fc2 in every block, everything else as the bf16 mode) on the tiny golden: finite,
     close to the bf16 mode, and its distance to the fp32 reference stated (fp8 operands: a few 1e-2 relative)."""
     gd = np.load(golden_dir / "vggt_tiny_conv.npz")
     cfg = W.VGGTConfig(**json.loads(str(gd["cfg_json"])))
@@ -150,8 +181,8 @@ def test_vggt_fp8_mode_against_reference(golden_dir):
 
 
 def test_vggt_fp8_fused_quantisation_path(monkeypatch):
-    """The block path of SKIMI_PREC_FP8 at a size where the quantisation rides in the producers (LayerNorm -> MXFP8, fc1's
-    GELU epilogue -> MXFP8 on the 256-row loop: 8 x 1374 = 10992 token rows x hidden 1024 = 172 tiles): against the fp32 CPU
+    """The block path of SKIMI_PREC_FP8 at a size where the quantisation rides in the producers (LayerNorm -> MXFP8, the attention kernel's
+    output rows -> MXFP8, fc1's GELU epilogue -> MXFP8 on the 256-row loop: 8 x 1374 = 10992 token rows x hidden 1024 = 172 tiles): against the fp32 CPU
     oracle, and against the same model with the fused path switched off (SKIMI_FP8_W4=0: separate quantisation passes of the
     bf16 activations).  The two fp8 variants differ by the bf16 rounding in front of the quantiser only."""
     from oracle import vggt_oracle
@@ -167,8 +198,10 @@ def test_vggt_fp8_fused_quantisation_path(monkeypatch):
     m.load_state_dict(sd)
     fused = m(images.cuda(), want={"camera"}, return_tokens=True)["tokens_last"].cpu().numpy()
     monkeypatch.setenv("SKIMI_FP8_W4", "0")        # re-read per launch: conftest sets SKIMI_ENV_DYNAMIC=1
+    monkeypatch.setenv("SKIMI_ATTN_MX", "0")       # proj's operand: a quantisation pass over the attention's bf16 rows
     plain = m(images.cuda(), want={"camera"}, return_tokens=True)["tokens_last"].cpu().numpy()
     monkeypatch.delenv("SKIMI_FP8_W4")
+    monkeypatch.delenv("SKIMI_ATTN_MX")
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
     print(f"tokens rel err vs oracle: fused {rel(fused.reshape(ref.shape), ref):.3e}, separate passes {rel(plain.reshape(ref.shape), ref):.3e}; "
           f"fused vs separate {rel(fused, plain):.3e}")
