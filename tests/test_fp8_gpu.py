@@ -158,6 +158,16 @@ def test_attention_mx_output(batch, seq, heads):
     assert (q8.cpu().numpy() == qr)[blk].mean() > 0.9
 
 
+def test_attention_mx_output_refuses_other_shapes():
+    """MXFP8 rows come from the 64-query bf16 kernel only: fp32 q / k / v, another head width or an odd number of heads
+    (a row of 32-channel blocks that is not a whole number of 128-column K-tiles) are refused, not mis-written."""
+    from skiing_analysis_pytorch_amd._lib import SkimiError
+    for dtype, heads, hd in ((torch.float32, 2, 64), (torch.bfloat16, 2, 48), (torch.bfloat16, 3, 64)):
+        qkv = torch.zeros(64, 3 * heads * hd, dtype=dtype, device="cuda")
+        with pytest.raises(SkimiError):
+            ops.attention(qkv, 1, 64, heads, hd, out_dtype="fp8mx")
+
+
 def test_vggt_fp8_mode_against_reference(golden_dir):
     """PREC_FP8 (MXFP8 qkv / proj / fc1 / fc2 in every block, everything else as the bf16 mode) on the tiny golden: finite,
     close to the bf16 mode, and its distance to the fp32 reference stated (fp8 operands: a few 1e-2 relative)."""
