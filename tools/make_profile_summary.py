@@ -62,7 +62,9 @@ for k, v in sorted(g.items(), key=lambda kv: -kv[1][0]):
     if 'attn' in k[0]:
         wg = int(k[1]) // int(k[2])
         if 'f32' in k[0]:
-            shape = "`attn_f32_kernel<128>`: camera-head trunk attention over the 8 camera tokens (fp32 kernel)"
+            shape = ("`attn_f32_kernel<64>`: the tracker's time / space attention (48-wide heads, fp32 kernel; grid x only: the launches are 3-D, q blocks x heads x sequences)"
+                     if '<64>' in k[0] else
+                     "`attn_f32_kernel<128>`: camera-head trunk attention over the 8 camera tokens (fp32 kernel)")
         elif wg == 2752:
             shape = "global attention: batch 4, seq 8 x 1374 = 10992, 16 heads x 64"; ga = v
         else:
