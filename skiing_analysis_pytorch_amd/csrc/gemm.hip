@@ -520,6 +520,17 @@ int gemm_dispatch(const skimi_gemm_desc* d, hipStream_t st, void* scratch, size_
         return rc256;
     }
 
+    // 3 x 3 convolutions to 128 channels on 16-bit operands (the track head's feature extractor): halo window in LDS
+    if (force_splitk <= 0 && conv_win_eligible(d)) {
+        const bool profw = prof_armed(PROF_GEMM, (long)d->M);
+        if (profw) prof_before(st);
+        const int rcw = conv_win_launch(a, st);
+        if (profw)
+            prof_after(st, 2.0 * d->M * (double)d->N * d->K,
+                       2.0 * d->M * (double)d->cC + 2.0 * d->N * (double)d->K + (d->out_dtype == SKIMI_F32 ? 4.0 : 2.0) * d->M * (double)d->N);
+        return rcw;
+    }
+
     // tile + split-K choice: fill >= ~256 CUs
     const long t128 = cdiv(d->M, 128) * cdiv(d->N, 128);
     const bool small = t128 < 128;

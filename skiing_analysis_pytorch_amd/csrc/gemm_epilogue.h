@@ -268,6 +268,9 @@ int split_planes_launch(const float* x, long ld, long rows, int C, void* hi, voi
 // fp32 [rows, C] -> records [rows][ceil(C/32)][hi 32 | lo 32] bf16 (operand form of the LDS-DMA bf16x3 kernel)
 int split_records_launch(const float* x, long ld, long rows, int C, void* rec, hipStream_t st, void* zpage = nullptr);
 int gemm256_launch(GemmArgs& a, hipStream_t st);
+// conv_win.hip: 3 x 3 / stride 1 / pad 1 -> 128 channels on single-term 16-bit operands, halo window in LDS
+bool conv_win_eligible(const skimi_gemm_desc* d);
+int conv_win_launch(GemmArgs& a, hipStream_t st);
 int gemm256_fp8_launch(GemmArgs& a, hipStream_t st);   // MXFP8 operands on the single-stream 256 x 256 loop; a.K = Kp (bytes per row)
 
 }  // namespace skimi
