@@ -11,8 +11,9 @@
 //   * 8 waves, wave w = output rows 2w, 2w+1 of the tile (32 pixels = one MFMA row block);
 //   * per 32-channel slice: 9 taps x 2 k-steps x {a_lo.w_hi, a_hi.w_lo, a_hi.w_hi} = 54
 //     v_mfma_f32_32x32x16_bf16 per wave on one 32 x 32 accumulator;
-//   * LDS rows are 64 B (32 bf16) per pixel / per (tap, cout); 16-B chunk ^= (row >> 2) & 3 on the
-//     DMA source and on the ds_read_b128 (conflict-free 64-B rows);
+//   * LDS rows are 64 B (32 bf16) per pixel / per (tap, cout); the 16-B chunk is XOR-swizzled on the DMA source and
+//     on the ds_read_b128: by (cout >> 2) & 3 for the weights, by ((hx + 2 hy) >> 2) & 3 for the window, whose second
+//     tile row is read with its columns rotated by two (conflict-free at the 18-pixel pitch: see the fragment addresses);
 //   * double-buffered slices: 2 x (2 planes x 21 KiB window + 2 planes x 18 KiB weights) = 156 KiB;
 //   * the epilogue stores straight from the accumulator layout: for every register 32 lanes hold
 //     the 32 output channels of one pixel = one full 128-B line.
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void conv_direct_n32_kernel(const ConvDirec
             const int px = 16 * q + (lane >> 2);
             const int hy = px / 18, hx = px - hy * 18;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const int sc = (lane & 3) ^ ((px >> 2) & 3);
+            const int sc = (lane & 3) ^ (((hx + 2 * hy) >> 2) & 3);
             if (px < CD_WIN && y >= 0 && y < p.H && x >= 0 && x < p.W)
                 in_off[j] = (((long)f * p.H + y) * p.W + x) * p.px_stride + sc * 8;
         }
@@ -138,14 +139,21 @@ __global__ __launch_bounds__(512, 2) void conv_direct_n32_kernel(const ConvDirec
         }
     };
 
-    // ---- fragment addresses: lane (l31, lh) of wave w reads pixel (2w + (l31 >> 4) + dy, (l31 & 15) + dx) ----
+    // ---- fragment addresses: lane (l31, lh) of wave w reads pixel (2w + (l31 >> 4) + dy, col(l31) + dx) ----
+    // The window's row pitch is 18 pixels = 4.5 bank rows of 256 B, so the second tile row of a fragment sits two pixels off
+    // the first inside a bank row.  Two measures make every ds_read_b128 conflict-free (checked against the instruction's
+    // four 16-lane groups, MI355X_MICROARCH.md §LDS; the first version's key (px >> 2) & 3 was a 2-way conflict on every
+    // A read): the chunk key follows u = hx + 2 hy, and the lanes of the second row take their columns rotated by two
+    // (col = (l31 + 14) & 15), so that a lane group's sixteen u values are distinct mod 16.
+    const int col = ((l31 & 15) + ((l31 >> 4) ? 14 : 0)) & 15;
     int a_off[9][2];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - dy * 3;
-        const int px = (2 * wave + (l31 >> 4) + dy) * 18 + (l31 & 15) + dx;
+        const int hy = 2 * wave + (l31 >> 4) + dy, hx = col + dx;
+        const int px = hy * 18 + hx;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) a_off[tap][ks] = px * 64 + (((2 * ks + lh) ^ ((px >> 2) & 3)) << 4);
+        for (int ks = 0; ks < 2; ++ks) a_off[tap][ks] = px * 64 + (((2 * ks + lh) ^ (((hx + 2 * hy) >> 2) & 3)) << 4);
     }
     int b_off[2];
 #pragma unroll
@@ -178,7 +186,8 @@ __global__ __launch_bounds__(512, 2) void conv_direct_n32_kernel(const ConvDirec
         __syncthreads();
     }
 
-    // ---- epilogue: register r of lane (cout = l31, lh) is pixel (r&3) + 8 (r>>2) + 4 lh of the wave's 32 ----
+    // ---- epilogue: register r of lane (cout = l31, lh) is MFMA row (r&3) + 8 (r>>2) + 4 lh of the wave's 32, i.e. pixel
+    //      (row >> 4, column rotated back by two in the second tile row) ----
     const float bs = p.bias ? p.bias[l31] : 0.f;
     const bool interior = y0 + 16 <= p.H && x0 + 16 <= p.W;   // block-uniform
     float* ob = p.out + ((long)f * p.H * p.W) * 32 + l31;
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void conv_direct_n32_kernel(const ConvDirec
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pix = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int y = y0 + 2 * wave + (pix >> 4), x = x0 + (pix & 15);
+            const int y = y0 + 2 * wave + (pix >> 4), x = x0 + (((pix & 15) + ((pix >> 4) ? 14 : 0)) & 15);
             float v = acc[r] + bs;
             if (p.relu) v = fmaxf(v, 0.f);
             ob[((long)y * p.W + x) * 32] = v;
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void conv_direct_n32_kernel(const ConvDirec
 #pragma unroll 1
         for (int r = 0; r < 16; ++r) {
             const int pix = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int y = y0 + 2 * wave + (pix >> 4), x = x0 + (pix & 15);
+            const int y = y0 + 2 * wave + (pix >> 4), x = x0 + (((pix & 15) + ((pix >> 4) ? 14 : 0)) & 15);
             float v = acc[r] + bs;
             if (p.relu) v = fmaxf(v, 0.f);
             if (y < p.H && x < p.W) ob[((long)y * p.W + x) * 32] = v;
