@@ -72,7 +72,7 @@ for k, v in sorted(g.items(), key=lambda kv: -kv[1][0]):
         out.append(f"| {v[1]/NS:.0f} | {k[1]} = {wg} WG x {k[2]} | {shape} | {v[0]/v[1]/1e3:.1f} |")
 if ga:
     out.append(f"\nThe {ga[0]/ga[1]/1e3:.0f} us of the global-attention launches under rocprofv3 against the {rf['avg_launch_us']:.0f} us that bench.py measures un-profiled (a different box; profiled passes also clock a few % lower, MI355X_MICROARCH.md cycle-constants note 2); {rf['flops_per_launch']/1e9:.1f} GFLOP per launch -> {rf['flops_per_launch']/(ga[0]/ga[1])/1e3:.0f} (profiled) / {rf['achieved']:.0f} (un-profiled) TFLOP/s.")
-out.append("\nTrack head rows (at the aggregator's 16-bit precision since round 3): `gemm_kernel<64, 64, 64, 1, float, unsigned short, 4, true>` + `layernorm_kernel<8>` + `attn_f32_kernel<64>` are the tracker's small launches (4 iterations x 6 rounds of time / space attention over the whole batch; fp32 activations rounded to fp16 while staged), `gemm_kernel<128, 128, 64, 1, float, unsigned short, 1, true>` its DPT feature extractor.")
+out.append("\nTrack head rows (at the aggregator's 16-bit precision since round 3): `gemm_kernel<64, 64, 64, 1, float, unsigned short, 4, true>` + `layernorm_kernel<8>` + `attn_f32_kernel<64>` are the tracker's small launches (4 iterations x 6 rounds of time / space attention over the whole batch; fp32 activations rounded to fp16 while staged), `conv_win128_kernel<F16>` the 3 x 3 convolutions of its DPT feature extractor (halo-window kernel, round 3; the small maps stay on `gemm_kernel<128, 128, 64, 1, unsigned short, unsigned short, 1, true>`).")
 out.append("\nGEMM shapes behind the `gemm256*` rows (M = 4 x 10992 = 43968 token rows; template argument = epilogue): `gemm256w4_kernel<1, F16>` qkv 1024->3072 (bias -> bf16 rows for the attention) and `gemm256w4_kernel<2, F16>` fc2 4096->1024 (bias, LayerScale, fp32 residual) on the single-stream 4-wave loop; `gemm256pp_kernel<3, 1, F16>` fc1 1024->4096 (bias, GELU -> fp16) and `gemm256pp_kernel<2, 1, F16>` proj 1024->1024 (residual epilogue) on the 8-wave ping-pong loop (F16 = true: fp16 operands on v_mfma_f32_32x32x16_f16).  `gemm_x3w4_kernel<a_mode>` / `gemm_x3w4n_kernel` (256- / 128-column tiles), `gemm_kernel<...,3,float,float>` and `conv_direct_n32_kernel` are the fp32-accurate (bf16x3) convolutions of the depth and point DPT heads; `bilinear_ac_planes_kernel` is the upsample that writes their bf16 hi|lo operands directly.")
 open(outp, 'w').write("\n".join(out) + "\n")
 print("\n".join(out)[:2500])
