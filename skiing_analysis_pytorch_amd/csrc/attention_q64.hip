@@ -25,8 +25,10 @@
 //     MFMA k-step whose K-side fragment is the unit vector e0 and whose Q-side fragment carries -r, so the
 //     accumulator is already s - r and v_exp2 takes it as it is.  r lives in bf16 (it has to pass through the
 //     operand), which is fine: softmax is invariant to the shift as long as every tile of a row uses the same one;
-//   * r is only moved when a tile's scores exceed it by more than 2^8 (lazy rescale, exact: O, the row sum and
-//     the tile's scores are shifted by the same r' - r), so after the first tiles the rescale branch is dead.
+//   * r is only moved when a tile runs away from it (lazy rescale, exact: O, the row sum and the tile's scores are
+//     shifted by the same r' - r), so after the first tiles the rescale branch is dead;
+//   * (round 3) and the test for that is on the tile's partial row SUM, which the loop forms anyway, not on a row
+//     maximum: after the first tile no v_max3 is issued at all (see the loop).
 // 4 extra MFMAs per 64-key tile (36 instead of 32) against 64 fewer VALU instructions per lane.
 //
 // Tried on top of this, no gain (2327-2344 us against 2307-2311 for the bench's global-attention launch):
@@ -133,7 +135,6 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
             for (int r = 0; r < 16; ++r) o[qi][dt][r] = 0.f;
     float lsum[2] = {0.f, 0.f};   // this lane's partial row sums (its 32 of every 64 keys)
     float mr[2] = {0.f, 0.f};     // row reference (log2 units, a bf16 value), set from the first tile
-    constexpr float THR = 8.f;    // scores may exceed the reference by 2^8 before it is moved
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // the extra k-step: K side = e0 for every key (element k = 0 sits in the lh = 0 half), Q side = -r of the lane's query
     bf16x8 kone = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -222,15 +223,64 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             // ---- online softmax: row = query = this lane pair (l31, both halves); s holds score - r ----
-            float mloc = -INFINITY;
+            // Fast path (every tile but the first): no row maximum at all.  The scores are exponentiated against the
+            // standing reference and only the tile's partial row sum is looked at: while it stays below 2^40 nothing can
+            // overflow (P, O and the row sum have > 80 binades of headroom) and softmax is invariant to where the reference
+            // sits, so the maximum -- 16 v_max3 + a cross-half swap + a vote per tile and query block, ~15 % of the VALU
+            // issue that is level with the MFMA time here -- is not needed.  A row whose scores run away from its reference
+            // trips the sum test (inf and NaN included); then the tile's scores are recomputed from the K tile still in LDS
+            // and the reference is moved by the exact procedure of the first tile.
+            bool redo = kt == 0;
+            if (kt != 0) {
+                // scalar VALU on purpose: packed-fp32 (VOP3P) ops do not co-issue with MFMAs (build.py)
+                float l0 = 0.f, l1 = 0.f;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mloc = __builtin_fmaxf(mloc, s[qi][t][r]);
-            mloc = xhalf_max(mloc);
-            // move the reference: always on the first tile (r := the tile's maximum), later only when some row's
-            // scores run more than 2^THR above it.  Exact: O, the row sum and this tile's scores shift together.
-            if (kt == 0 || __any(mloc > THR)) {
+                    for (int r = 0; r < 16; r += 2) {
+                        float v0 = s[qi][t][r], v1 = s[qi][t][r + 1];
+                        if (!(dbg & 2)) {
+                            v0 = __builtin_amdgcn_exp2f(v0);
+                            v1 = __builtin_amdgcn_exp2f(v1);
+                        }
+                        l0 += v0;
+                        l1 += v1;
+                        s[qi][t][r] = v0;
+                        s[qi][t][r + 1] = v1;
+                    }
+                const float ts = l0 + l1;
+                redo = __any(!(ts < 1.099511627776e12f));   // 2^40
+                if (!redo) lsum[qi] += ts;
+            }
+            if (redo) {   // wave-uniform
+                if (kt != 0) {
+                    // the scores again (the fast path overwrote them with their exponentials)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int row = t * 32 + l31;
+                        s[qi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kone, qneg[qi], zero16, 0, 0, 0);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const bf16x8 kr = *reinterpret_cast<const bf16x8*>(kb + row * 128 + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4));
+                            s[qi][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr, qf[qi][ks], s[qi][t], 0, 0, 0);
+                        }
+                        if (ragged && kt == nkt - 1) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int key = kt * KV + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                if (key >= a.seq_k) s[qi][t][r] = -INFINITY;
+                            }
+                        }
+                    }
+                }
+                float mloc = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mloc = __builtin_fmaxf(mloc, s[qi][t][r]);
+                mloc = xhalf_max(mloc);
+                // move the reference: r := the tile's maximum on the first tile, r += max(tile maximum, 0) later.
+                // Exact: O, the row sum and this tile's scores shift together.
                 const float want = mr[qi] + (kt == 0 ? mloc : __builtin_fmaxf(mloc, 0.f));
                 const float mnew = bf2f(f2bf(want));          // the reference has to be a bf16 value
                 const float dlt = mnew - mr[qi];              // exact in fp32
@@ -243,30 +293,25 @@ __global__ __launch_bounds__(256, 2) void attn_q64_kernel(const AttnArgs a, int 
                     }
                     lsum[qi] *= alpha;
                 }
+                mr[qi] = mnew;
+                qneg[qi][0] = lh == 0 ? (short)f2bf(-mnew) : (short)0;
+                float l0 = 0.f, l1 = 0.f;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s[qi][t][r] -= dlt;
-                mr[qi] = mnew;
-                qneg[qi][0] = lh == 0 ? (short)f2bf(-mnew) : (short)0;
-            }
-            // scalar VALU on purpose: packed-fp32 (VOP3P) ops do not co-issue with MFMAs (build.py)
-            float l0 = 0.f, l1 = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    float v0 = s[qi][t][r], v1 = s[qi][t][r + 1];
-                    if (!(dbg & 2)) {
-                        v0 = __builtin_amdgcn_exp2f(v0);
-                        v1 = __builtin_amdgcn_exp2f(v1);
+                    for (int r = 0; r < 16; r += 2) {
+                        float v0 = s[qi][t][r] - dlt, v1 = s[qi][t][r + 1] - dlt;
+                        if (!(dbg & 2)) {
+                            v0 = __builtin_amdgcn_exp2f(v0);
+                            v1 = __builtin_amdgcn_exp2f(v1);
+                        }
+                        l0 += v0;
+                        l1 += v1;
+                        s[qi][t][r] = v0;
+                        s[qi][t][r + 1] = v1;
                     }
-                    l0 += v0;
-                    l1 += v1;
-                    s[qi][t][r] = v0;
-                    s[qi][t][r + 1] = v1;
-                }
-            lsum[qi] += l0 + l1;
+                lsum[qi] += l0 + l1;
+            }
 
             // ---- O^T += V^T P^T (P = the S^T accumulator as bf16, k order of attention_bf16.hip) ----
 #pragma unroll
