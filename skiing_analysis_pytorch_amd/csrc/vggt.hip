@@ -67,6 +67,7 @@ struct DptW {
     int n_out = 0, features = 0, oc[4] = {0, 0, 0, 0};
     bool feature_only = false, pos_embed = true;
     bool out_f32 = false;   // feature_only heads: the returned feature map is fp32 whatever the activation format (the tracker reads fp32)
+    const LNw* out_ln = nullptr;   // feature_only heads with 128 features: LayerNorm applied by the last upsample (the tracker's fmap_norm)
     int down_ratio = 1;
 };
 struct CamW {
@@ -564,6 +565,12 @@ const UvTab* find_uv(const ShapeTabs* h, int w, int hh, int C) {
     return nullptr;
 }
 
+// whether a feature_only head's last upsample also applies the consumer's LayerNorm (SKIMI_TRACK_LN_FUSED=0: separate pass)
+bool dpt_fused_ln(const DptW& w, int f2, int udt) {
+    static const bool off = getenv("SKIMI_TRACK_LN_FUSED") && !atoi(getenv("SKIMI_TRACK_LN_FUSED"));
+    return !off && w.feature_only && w.out_ln != nullptr && w.out_ln->g != nullptr && w.out_ln->b != nullptr && f2 == 128 && udt == SKIMI_F32;
+}
+
 // DPT head (vggt/vggt/heads/dpt_head.py:172-291) on the kept intermediates.
 // Returns the NHWC feature map pointer for feature_only heads; otherwise writes pts / conf.
 void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, int P, int nsp, int ph, int pw, int C,
@@ -784,7 +791,10 @@ void* run_dpt(Ctx& c, const DptW& w, float* const* sf, float* const* sg, int F, 
         void* c1u = c.ar.alloc((size_t)F * Ho * Wo * f2 * Ctx::esz(udt));
         // upsample to the output size with the UV positional embedding added in the same pass
         if (!c.rc && !c.dry())
-            c.rc = bilinear_ac_launch(c1, c1u, adt, F, h1, w1, Ho, Wo, f2, c.st, uvt ? uvt->tx : nullptr, uvt ? uvt->ty : nullptr, udt);
+            c.rc = dpt_fused_ln(w, f2, udt)
+                       ? bilinear_ac_launch(c1, c1u, adt, F, h1, w1, Ho, Wo, f2, c.st, uvt ? uvt->tx : nullptr, uvt ? uvt->ty : nullptr, udt,
+                                            w.out_ln->g, w.out_ln->b, 1e-5f)
+                       : bilinear_ac_launch(c1, c1u, adt, F, h1, w1, Ho, Wo, f2, c.st, uvt ? uvt->tx : nullptr, uvt ? uvt->ty : nullptr, udt);
         if (w.feature_only) return c1u;   // caller releases the arena
         c2 = c.ar.alloc((size_t)F * Ho * Wo * 32 * es);
         auto d = c.desc(w.oc2a.lin, c1u, adt, f2, F * Ho * Wo, c2, adt, 32);

@@ -11,7 +11,8 @@ int bilinear_ac_planes_launch(const float* in, unsigned short* out, int N, int h
                               const float* tabx = nullptr, const float* taby = nullptr,
                               int slice_records = 0, void* zpage = nullptr);   // out: [N, H, W, hi C | lo C] bf16
 int bilinear_ac_launch(const void* in, void* out, int dtype, int N, int h, int w, int H, int W, int C,
-                       hipStream_t st, const float* tabx = nullptr, const float* taby = nullptr, int out_dtype = -1);   // out_dtype -1: the input's; SKIMI_F32 from a 16-bit map
+                       hipStream_t st, const float* tabx = nullptr, const float* taby = nullptr, int out_dtype = -1,   // out_dtype -1: the input's; SKIMI_F32 from a 16-bit map
+                       const float* ln_g = nullptr, const float* ln_b = nullptr, float ln_eps = 0.f);   // C == 128, fp32 out: LayerNorm of every resized pixel in the same pass
 int add_uv_pos_launch(void* x, int dtype, const float* tabx, const float* taby, int N, int H, int W, int C,
                       hipStream_t st);
 int adaln_launch(const float* xn, const float* x, const float* mod, float* out, long rows, int D, hipStream_t st);

@@ -90,11 +90,16 @@ int special_tokens_launch(float* x, const float* table, int F, int S, int P, int
 //   l1 = clamp(src - i0, 0, 1), out = l0y*(l0x*p00 + l1x*p01) + l1y*(l0x*p10 + l1x*p11)
 // ---------------------------------------------------------------------------------------
 // T / TO: element type of the input / output map (float, or unsigned short = a 16-bit format: bf16, or fp16 when f16 is set)
-template <typename T, typename TO = T>
+// LN: the resized pixel's C = 128 channels (one 32-lane group, 4 channels per lane) are LayerNorm'ed before they are stored
+// (the track head's fmap_norm over the feature map it has just resized, base_track_predictor.py:103-106: two-pass mean /
+// variance as layernorm_kernel, reduced inside the 32-lane group) -- no fp32 round trip of the 1.1 GB map
+template <typename T, typename TO = T, bool LN = false>
 __global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ in, TO* __restrict__ out, int N,
                                                           int h, int w, int H, int W, int C,
                                                           const float* __restrict__ tabx,
-                                                          const float* __restrict__ taby, bool f16 = false) {
+                                                          const float* __restrict__ taby, bool f16 = false,
+                                                          const float* __restrict__ ln_g = nullptr,
+                                                          const float* __restrict__ ln_b = nullptr, float ln_eps = 0.f) {
     // one output row (n, Y) per blockIdx.y; threads run over X * C/4: only 32-bit index math
     const int C4 = C / 4;
     const int rowlen = W * C4;
@@ -136,6 +141,26 @@ __global__ __launch_bounds__(256) void bilinear_ac_kernel(const T* __restrict__ 
             const float4 e = *reinterpret_cast<const float4*>(c < half ? tabx + (long)X * half + c
                                                                         : taby + (long)Y * half + (c - half));
             r[0] += e.x; r[1] += e.y; r[2] += e.z; r[3] += e.w;
+        }
+        if constexpr (LN) {   // C == 128: lanes 32 g .. 32 g + 31 hold one pixel (rowlen is a multiple of 32: whole groups run)
+            float s = (r[0] + r[1]) + (r[2] + r[3]);
+#pragma unroll
+            for (int o_ = 16; o_ > 0; o_ >>= 1) s += __shfl_xor(s, o_, 32);
+            const float mean = s * (1.0f / 128.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[k] -= mean;
+                q += r[k] * r[k];
+            }
+#pragma unroll
+            for (int o_ = 16; o_ > 0; o_ >>= 1) q += __shfl_xor(q, o_, 32);
+            const float rstd = rsqrtf(q * (1.0f / 128.0f) + ln_eps);
+            const float4 g4 = *reinterpret_cast<const float4*>(ln_g + c4 * 4), b4 = *reinterpret_cast<const float4*>(ln_b + c4 * 4);
+            r[0] = r[0] * rstd * g4.x + b4.x;
+            r[1] = r[1] * rstd * g4.y + b4.y;
+            r[2] = r[2] * rstd * g4.z + b4.z;
+            r[3] = r[3] * rstd * g4.w + b4.w;
         }
         TO* o = out + ((n * H + Y) * (long)W + X) * C + c4 * 4;
         if (sizeof(TO) == 4) {
@@ -233,8 +258,24 @@ int bilinear_ac_planes_launch(const float* in, unsigned short* out, int N, int h
 }
 
 int bilinear_ac_launch(const void* in, void* out, int dtype, int N, int h, int w, int H, int W, int C,
-                       hipStream_t st, const float* tabx, const float* taby, int out_dtype) {
+                       hipStream_t st, const float* tabx, const float* taby, int out_dtype, const float* ln_g, const float* ln_b,
+                       float ln_eps) {
     if (out_dtype < 0) out_dtype = dtype;
+    if (ln_g != nullptr) {   // resize + LayerNorm over the 128 channels of every output pixel, fp32 out
+        SKIMI_CHECK_ARG(ln_b != nullptr && C == 128 && out_dtype == SKIMI_F32 && (((uintptr_t)ln_g | (uintptr_t)ln_b) & 15) == 0,
+                        "bilinear resize + LayerNorm: C == 128, fp32 output, 16-byte aligned gamma / beta");
+        SKIMI_CHECK_ARG(tabx == nullptr || taby != nullptr, "fused uv pos embed needs both tables");
+        SKIMI_CHECK_ARG((long)N * H < 65536, "bilinear resize: N * H must be < 65536");
+        const dim3 grid((unsigned)cdiv((long)W * (C / 4), 256), (unsigned)(N * H));
+        if (dtype == SKIMI_F32)
+            hipLaunchKernelGGL((bilinear_ac_kernel<float, float, true>), grid, dim3(256), 0, st, (const float*)in, (float*)out, N, h, w,
+                               H, W, C, tabx, taby, false, ln_g, ln_b, ln_eps);
+        else
+            hipLaunchKernelGGL((bilinear_ac_kernel<unsigned short, float, true>), grid, dim3(256), 0, st, (const unsigned short*)in,
+                               (float*)out, N, h, w, H, W, C, tabx, taby, dtype == SKIMI_F16, ln_g, ln_b, ln_eps);
+        SKIMI_LAUNCH_CHECK();
+        return SKIMI_OK;
+    }
     SKIMI_CHECK_ARG(out_dtype == dtype || (dtype != SKIMI_F32 && out_dtype == SKIMI_F32),
                     "bilinear resize: the output type is the input's, or fp32 from a 16-bit map");
     SKIMI_CHECK_ARG(C % 4 == 0, "bilinear resize needs C %% 4 == 0");
